@@ -1,0 +1,146 @@
+"""Pins the oracle (oracle/voxurf_oracle.py, our CPU restatement) against golden vectors that were
+produced by the reference's own Python (oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import voxurf_oracle as O
+from tests.helpers import assert_close, load, oracle_step_from_golden, params_from_npz, scene_for
+
+
+def test_pose_algebra_matches_reference():
+    d = load('pose.npz')
+    wu = torch.tensor(d['wu'], requires_grad=True)
+    SE3 = O.se3_to_SE3(wu)
+    assert np.array_equal(SE3.detach().numpy(), d['SE3'])
+    comp = O.pose_compose_pair(SE3, torch.tensor(d['init']))
+    assert np.array_equal(comp.detach().numpy(), d['composed'])
+    inv = O.pose_invert(comp)
+    assert np.array_equal(inv.detach().numpy(), d['inverted'])
+    (inv * torch.tensor(d['wsum'])).sum().backward()
+    assert_close(wu.grad, d['grad_wu'], rtol=1e-6, atol=1e-7, name='grad_wu')
+
+
+def test_rays_match_reference_bit_exact():
+    d = load('rays.npz')
+    Ks, c2w = torch.tensor(d['Ks']), torch.tensor(d['c2w'])
+    H, W = 8, 12
+    for v in range(3):
+        for inv_y in (True, False):
+            tag = f'v{v}_invy{int(inv_y)}'
+            o, dd, vd = O.rays_of_view(H, W, Ks[v], c2w[v], inverse_y=inv_y, normalize=True)
+            assert np.array_equal(o.numpy(), d[f'vox_o_{tag}'])
+            assert np.array_equal(dd.numpy(), d[f'vox_d_{tag}'])
+            assert np.array_equal(vd.numpy(), d[f'vox_v_{tag}'])
+            o, dd, vd = O.rays_of_view(H, W, Ks[v], c2w[v], inverse_y=inv_y, normalize=False)
+            assert np.array_equal(dd.numpy(), d[f'dvgo_d_{tag}'])
+            assert np.array_equal(vd.numpy(), d[f'dvgo_v_{tag}'])
+
+
+@pytest.mark.parametrize('tag', ['g8', 'g24'])
+def test_dense_sampler_bit_exact(tag):
+    d = load(f'sampler_{tag}.npz')
+    scene = scene_for(d['G'])
+    ro, rd = torch.tensor(d['rays_o']), torch.tensor(d['rays_d'])
+    for sfx, jit in (('train', torch.tensor(d['jitter'])), ('eval', None)):
+        pts, mask_out, step, t_min, t_max = O.sample_dense(scene, ro, rd, jit)
+        assert np.array_equal(mask_out.numpy(), d[f'mask_out_{sfx}'])
+        assert np.array_equal(step.numpy(), d[f'step_{sfx}'])
+        assert np.array_equal(pts.numpy(), d[f'pts_{sfx}'])
+        assert np.array_equal(t_min.numpy(), d[f't_min_{sfx}'])
+        assert np.array_equal(t_max.numpy(), d[f't_max_{sfx}'])
+
+
+@pytest.mark.parametrize('tag', ['g8_s10', 'g24_s10', 'g24_s7000'])
+def test_forward_losses_and_all_gradients(tag):
+    d = load(f'forward_{tag}.npz')
+    out, S, loss, P, se3, aux = oracle_step_from_golden(d)
+    # rays, indices: bit exact
+    for k in ('rays_o', 'rays_d', 'viewdirs', 'target'):
+        assert np.array_equal(aux[k].detach().numpy(), d[k]), k
+    assert np.array_equal(out['mask'].numpy(), d['out.mask'])
+    # forward values
+    for k in ('alphainv_cum', 'weights', 'cum_weights', 'rgb_marched', 'raw_alpha', 'raw_rgb', 'depth', 'disp',
+              'gradient', 'k0_tv', 'sdf_deform', 'grad_deform', 'sdf_correct'):
+        assert_close(out[k], d['out.' + k], rtol=2e-5, atol=2e-6, name=k)
+    assert abs(out['s_val'] - float(d['out.s_val'])) < 1e-12
+    for k, v in S.items():
+        assert_close(v, d['loss.' + k], rtol=2e-5, atol=1e-7, name='loss.' + k)
+    assert_close(loss, d['loss'], rtol=2e-5, name='loss')
+    # gradients of every trainable tensor and of the pose
+    assert_close(se3.grad, d['grad.se3'], rtol=2e-4, atol=1e-6, name='grad.se3')
+    assert_close(P['k0'].grad, d['grad.k0'], rtol=1e-4, atol=1e-8, name='grad.k0')
+    assert_close(P['sdf_alpha'].grad, d['grad.sdf_alpha'], rtol=1e-4, atol=1e-7, name='grad.sdf_alpha')
+    assert_close(P['sdf_beta'].grad, d['grad.sdf_beta'], rtol=1e-4, atol=1e-7, name='grad.sdf_beta')
+    for li in range(4):
+        assert_close(P['rgbnet'][li][0].grad, d[f'grad.rgbnet.{li}.weight'], rtol=1e-4, atol=1e-8, name=f'rgbnet{li}.W')
+        assert_close(P['rgbnet'][li][1].grad, d[f'grad.rgbnet.{li}.bias'], rtol=1e-4, atol=1e-8, name=f'rgbnet{li}.b')
+    for li in range(5):
+        assert_close(P['warp'][li][0].grad, d[f'grad.warp.{li}.weight'], rtol=1e-4, atol=1e-7, name=f'warp{li}.W')
+        assert_close(P['warp'][li][1].grad, d[f'grad.warp.{li}.bias'], rtol=1e-4, atol=1e-7, name=f'warp{li}.b')
+
+
+def test_inference_matches_reference():
+    d = load('inference_g24.npz')
+    scene = scene_for(d['G'])
+    P = params_from_npz(d)
+    out = O.voxurf_inference(P, scene, torch.tensor(d['rays_o']), torch.tensor(d['rays_d']),
+                             torch.tensor(d['viewdirs']), global_step=None)
+    assert np.array_equal(out['mask_outbbox'].numpy(), d['out.mask_outbbox'])
+    for k in ('alphainv_cum', 'weights', 'cum_weights', 'rgb_marched', 'normal_marched', 'raw_alpha', 'raw_rgb',
+              'depth', 'gradient', 'gradient_error'):
+        assert_close(out[k], d['out.' + k], rtol=2e-5, atol=2e-6, name=k)
+
+
+def test_dvgo_forward_and_grads():
+    d = load('dvgo_g16.npz')
+    scene = O.Scene(scene_for(16).xyz_min, scene_for(16).xyz_max, 16 ** 3, stepsize=0.5, bg=1., viewbase_pe=4)
+    density = torch.tensor(d['density'], requires_grad=True)
+    k0 = torch.tensor(d['k0'], requires_grad=True)
+    rgbnet = [(torch.tensor(d[f'rgbnet.{li}.weight'], requires_grad=True),
+               torch.tensor(d[f'rgbnet.{li}.bias'], requires_grad=True)) for li in range(3)]
+    out = O.dvgo_forward(density, k0, rgbnet, scene, torch.tensor(d['rays_o']), torch.tensor(d['rays_d']),
+                         torch.tensor(d['viewdirs']), jitter=torch.tensor(d['jitter']), global_step=5,
+                         fast_color_thres=1e-4)
+    assert np.array_equal(out['mask_outbbox'].numpy(), d['out.mask_outbbox'])
+    assert np.array_equal(out['mask'].numpy(), d['out.mask'])
+    for k in ('alphainv_cum', 'weights', 'rgb_marched', 'raw_alpha', 'raw_rgb', 'depth'):
+        assert_close(out[k], d['out.' + k], rtol=1e-5, atol=1e-6, name=k)
+    loss = ((out['rgb_marched'] - torch.tensor(d['target'])) ** 2).mean()
+    loss.backward()
+    assert_close(density.grad, d['grad_density'], rtol=1e-4, atol=1e-9, name='grad_density')
+    assert_close(k0.grad, d['grad_k0'], rtol=1e-4, atol=1e-9, name='grad_k0')
+    for li in range(3):
+        assert_close(rgbnet[li][0].grad, d[f'grad.rgbnet.{li}.weight'], rtol=1e-4, atol=1e-9, name=f'W{li}')
+
+
+def test_adam_trajectory():
+    d = load('adam.npz')
+    p = torch.tensor(d['p0'])
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    lr = 0.1
+    for s in range(3):
+        lr *= 0.1 ** (1 / 10000)
+        O.adam_update(p, torch.tensor(d['grads'][s]), m, v, s + 1, lr)
+        assert np.array_equal(p.numpy(), d['traj'][s])
+    assert np.array_equal(m.numpy(), d['exp_avg'])
+    assert np.array_equal(v.numpy(), d['exp_avg_sq'])
+
+
+def test_alpha2weight_known_answers():
+    """Hand-checked segments (the compiled CUDA kernel itself is 'parity unpinned'):
+    empty ray, single sample, early termination at T<1e-3 with untouched tail (w=0,T=1)."""
+    from oracle import native_ops
+    alpha = torch.tensor([0.5, 0.5, 0.9999, 0.3, 0.2, 0.25])
+    ray_id = torch.tensor([0, 0, 2, 2, 2, 3])
+    w, T, last, i_s, i_e = native_ops.alpha2weight(alpha, ray_id, 5)
+    assert_close(w, [0.5, 0.25, 0.9999, 0.0, 0.0, 0.25], rtol=1e-6, atol=1e-7)
+    assert_close(T, [1, 0.5, 1, 1, 1, 1], rtol=1e-6)
+    assert_close(last, [0.25, 1.0, 1 - 0.9999, 0.75, 1.0], rtol=1e-3, atol=1e-7)
+    assert i_s.tolist() == [0, 0, 2, 5, 0] and i_e.tolist() == [2, 0, 3, 6, 0]
+    gw = torch.tensor([1., 2., 3., 4., 5., 6.])
+    gl = torch.tensor([0.5, 0.5, 0.5, 0.5, 0.5])
+    g = native_ops.alpha2weight_backward(alpha, w, T, last, i_s, i_e, 5, gw, gl)
+    # ray 0 by hand: back=.5*.25=.125; i=1: g=2*.5-.125/.5=.75, back=.125+2*.25=.625; i=0: g=1-.625/.5=-.25
+    assert_close(g[:2], [-0.25, 0.75], rtol=1e-5)
+    assert g[3] == 0 and g[4] == 0            # beyond the early stop: no gradient
