@@ -1,0 +1,226 @@
+/* poseprobe_hip.h - C ABI of libposeprobe_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for PoseProbe's object-branch hot path.  It replaces the reference's pybind11
+ * torch extension `render_utils_cuda` (lib/cuda/render_utils.cpp:170-184) and the eager-PyTorch op
+ * chains of lib/voxurf_coarse.py / lib/dvgo_ori.py / lib/camera.py / lib/losses.py / lib/utils.py
+ * listed per entry point below (file:line relative to the reference tree).
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch / ATen types;
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the CALLER owns every buffer
+ *     (inputs, outputs, workspace) - the library never allocates and never synchronises;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are re-entrant;
+ *   - sample counts that are data dependent (M) live in device memory (`count`, one int32) so that a
+ *     whole train step can be enqueued / graph-captured without a host round trip; kernels are
+ *     launched for the capacity and retire surplus work-groups immediately;
+ *   - fp32 values, int32 indices (the Python shim converts to int64 where the reference returns it);
+ *   - return value: 0 on success, negative pp_status otherwise; pp_last_error() gives the text of
+ *     the last failure on the calling thread.
+ */
+#ifndef POSEPROBE_HIP_H
+#define POSEPROBE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  PP_OK = 0,
+  PP_ERR_INVALID_ARG = -1,
+  PP_ERR_LAUNCH = -2,
+  PP_ERR_UNSUPPORTED = -3
+} pp_status;
+
+const char* pp_last_error(void);
+int pp_abi_version(void);
+
+/* Static description of the voxel scene; mirrors the attributes Voxurf derives in __init__ /
+ * _set_grid_resolution (lib/voxurf_coarse.py:67-68, :319-323) and the render_kwargs
+ * (lib/recon_scene.py:208-217). */
+typedef struct {
+  float xyz_min[3];
+  float xyz_max[3];
+  int32_t size[3];      /* world_size X,Y,Z */
+  float voxel_size;     /* fp32 value of Voxurf.voxel_size */
+  float stepsize;       /* in voxels */
+  float near_clip;
+  float far_clip;
+  float bg;
+  int32_t n_samples;    /* S = int(|world_size+1| / stepsize) + 1  (voxurf_coarse.py:700) */
+  float out_range;      /* DeformedImplicitField.output_range (deform_net.py:17) */
+  int32_t k0_dim;       /* 12 */
+  int32_t pos_pe;       /* 5 */
+  int32_t view_pe;      /* 1 */
+} pp_scene;
+
+/* ---------------------------------------------------------------- pose: lib/camera.py:76-99,127-188;
+ * lib/recon_scene.py:62-74 (get_current_pose_pnp) + camera.pose.invert (recon_scene.py:444).
+ * se3[V,6], w2c_init[V,3,4] -> w2c[V,3,4], c2w[V,3,4]; jac[V,12,6] = d c2w / d se3 (forward mode),
+ * consumed by pp_pose_bwd: se3_grad[V,6] = jac^T c2w_grad.  refine_mask[V] (0 = view is not refined). */
+int pp_pose_fwd(const float* se3, const float* w2c_init, const int32_t* refine_mask, int32_t n_views,
+                float* w2c, float* c2w, float* jac, void* stream);
+int pp_pose_bwd(const float* jac, const float* c2w_grad, int32_t n_views, float* se3_grad, void* stream);
+
+/* ---------------------------------------------------------------- rays: lib/voxurf_coarse.py:1339-1368,
+ * :1402-1407, :1518-1549 + the randperm selection (recon_scene.py:598-600), index-first: only the selected
+ * pixels are generated.  ray_idx[N] indexes the flattened [V,H,W] pixel list.  normalize=1: Voxurf
+ * variant (rays_d = viewdirs), 0: DVGO variant (dvgo_ori.py:562-563).  images[V,H,W,3], masks[V,H,W].
+ * Also performs the slab test of sample_ray_ori (voxurf_coarse.py:702-708): t_min,t_max[N]. */
+int pp_raygen_select_fwd(const pp_scene* sc, const int32_t* ray_idx, int32_t n_rays, const float* c2w,
+                         const float* intr /*[V,4] fx,fy,cx,cy*/, int32_t n_views, int32_t H, int32_t W,
+                         int32_t inverse_y, int32_t normalize, const float* images, const float* masks,
+                         float* rays_o, float* rays_d, float* viewdirs, float* target, float* mask_px,
+                         void* stream);
+/* Backward of the above plus of the dense sampler's ray-level terms: consumes per-sample gradients
+ * (pts_grad[M,3], step[M], viewdir_grad_s[M,3]) segmented by ray_start[N+1], optional direct grads
+ * on rays (may be NULL); produces per-ray grads rays_o/rays_d/viewdirs_grad_out[N,3] (any may be NULL) and,
+ * when c2w_grad != NULL (Voxurf ray variant), c2w_grad[V,3,4] (zeroed by the callee). */
+int pp_raygen_select_bwd(const pp_scene* sc, const int32_t* ray_idx, int32_t n_rays, const float* c2w,
+                         const float* intr, int32_t n_views, int32_t H, int32_t W, int32_t inverse_y,
+                         const float* rays_o, const float* rays_d, const float* t_min,
+                         const int32_t* ray_start, const float* pts_grad, const float* step,
+                         const float* viewdir_grad_s, const float* rays_o_grad, const float* rays_d_grad,
+                         const float* viewdirs_grad, const float* depth_grad, float* rays_o_grad_out,
+                         float* rays_d_grad_out, float* viewdirs_grad_out, float* c2w_grad, void* stream);
+
+/* ---------------------------------------------------------------- dense sampler + compaction:
+ * Voxurf.sample_ray_ori (voxurf_coarse.py:697-719) followed by the boolean compaction (:936-945).
+ * jitter[N] may be NULL (eval).  Outputs: t_min,t_max[N], ray_start[N+1] (exclusive prefix of the
+ * per-ray in-bbox counts; ray_start[N] = M, also written to count[0]), pts[M,3], ray_id[M],
+ * step_k[M] (sample index within the ray), step[M] (= stepsize*voxel_size*(k+jitter)),
+ * mask_keep[N*S] (uint8, 1 = in bbox; may be NULL).  capacity = allocated rows of the per-sample outputs. */
+int pp_sample_dense(const pp_scene* sc, const float* rays_o, const float* rays_d, const float* jitter,
+                    int32_t n_rays, int32_t capacity, float* t_min, float* t_max, int32_t* ray_start,
+                    int32_t* count, float* pts, int32_t* ray_id, int32_t* step_k, float* step,
+                    uint8_t* mask_keep, void* stream);
+
+/* Variable-length sampler of the reference's CUDA extension: sample_pts_on_rays
+ * (lib/cuda/render_utils_kernel.cu:12-242) as used by Voxurf.sample_ray_cuda (voxurf_coarse.py:661-695,
+ * far forced to 1e9, points recomputed as rays_start + dir*step_id*stepdist, in-bbox compaction).
+ * n_steps[N] are the raw per-ray counts (kernel.cu:38-55); ray_start[N+1] prefix of the kept samples. */
+int pp_sample_var(const pp_scene* sc, const float* rays_o, const float* rays_d, int32_t n_rays,
+                  int32_t capacity, float* t_min, float* t_max, int32_t* n_steps, int32_t* ray_start,
+                  int32_t* count, float* pts, int32_t* ray_id, int32_t* step_id, void* stream);
+
+/* ---------------------------------------------------------------- transmittance scan:
+ * render_utils_cuda.alpha2weight / alpha2weight_backward (lib/cuda/render_utils_kernel.cu:577-707, bound
+ * at lib/voxurf_coarse.py:1319,:1329).  ray_start[N+1] replaces the kernel's i_start/i_end bookkeeping
+ * (kernel.cu:607-636).  One wavefront per ray; sequential-order products, 1e-3 early stop. */
+int pp_alpha2weight_fwd(const float* alpha, const int32_t* ray_start, int32_t n_rays, float* weights,
+                        float* T, float* alphainv_last, int32_t* i_end, void* stream);
+int pp_alpha2weight_bwd(const float* alpha, const float* weights, const float* T, const float* alphainv_last,
+                        const int32_t* ray_start, const int32_t* i_end, int32_t n_rays,
+                        const float* grad_weights, const float* grad_last, float* grad_alpha, void* stream);
+
+/* Fused scan + compositing (replaces Alphas2Weights + the segment_coo calls, voxurf_coarse.py:995,
+ * :1034-1057 / inference :1179-1202): rgb_marched[N,3] (clamped), rgb_pre[N,3] (pre-clamp, for the
+ * backward), cum_weights[N], depth_acc[N] = sum w*step_w (step_w[M]: train `step`, inference
+ * step_id*dist), optional normal_marched[N,3] from nrm_in[M,3] (may be NULL). */
+int pp_march_fwd(const float* alpha, const float* rgb, const float* step_w, const float* nrm_in,
+                 const int32_t* ray_start, int32_t n_rays, float bg, float* weights, float* T,
+                 float* alphainv_last, int32_t* i_end, float* rgb_marched, float* rgb_pre,
+                 float* cum_weights, float* depth_acc, float* normal_marched, void* stream);
+int pp_march_bwd(const float* alpha, const float* rgb, const float* step_w, const float* weights, const float* T,
+                 const float* alphainv_last, const int32_t* ray_start, const int32_t* i_end, int32_t n_rays,
+                 float bg, const float* rgb_pre, const float* g_rgb_marched, const float* g_cum_weights,
+                 const float* g_alphainv_last, const float* g_depth_acc, const float* g_weights /*[M] or NULL*/,
+                 float* grad_alpha, float* grad_rgb, void* stream);
+
+/* ---------------------------------------------------------------- geometry: sdf mapping
+ * (voxurf_coarse.py:946-949), custom trilinear lookup at deformed / undeformed points (:545-659, :967,
+ * :978), spatial gradients (:968-984) and NeuS alpha (:483-519), fused.  The mapped grid is never
+ * materialised: the 8 corner values are mapped in registers.
+ * warp_out[M,4,4]: row 0 = (deform xyz, correction), rows 1-3 = d/dp_i of the same (already x out_range).
+ * Outputs: alpha[M], gradient[M,3], sdf_final[M], sdf_deform[M], grad_deform[M,3,3]. */
+int pp_geometry_fwd(const pp_scene* sc, const float* sdf_grid, const float* sdf_ab /*[2] raw alpha,beta*/,
+                    const float* pts, const float* warp_out, const float* viewdirs, const int32_t* ray_id,
+                    const int32_t* count, int32_t capacity, float inv_s, float* alpha, float* gradient,
+                    float* sdf_final, float* sdf_deform, float* grad_deform, void* stream);
+/* Upstream grads (any may be NULL): g_alpha[M], g_gradient[M,3], g_sdf_final[M], g_sdf_deform[M],
+ * g_grad_deform[M,9], g_correction[M].  Outputs: warp_out_grad[M,4,4], pts_grad[M,3] (accumulate=1: +=),
+ * viewdir_grad_s[M,3] (+= if accumulate), sdf_ab_grad[2] (atomic +=; caller zeroes). */
+int pp_geometry_bwd(const pp_scene* sc, const float* sdf_grid, const float* sdf_ab, const float* pts,
+                    const float* warp_out, const float* viewdirs, const int32_t* ray_id, const int32_t* count,
+                    int32_t capacity, float inv_s, const float* g_alpha, const float* g_gradient,
+                    const float* g_sdf_final, const float* g_sdf_deform, const float* g_grad_deform,
+                    const float* g_correction, int32_t accumulate, float* warp_out_grad, float* pts_grad,
+                    float* viewdir_grad_s, float* sdf_ab_grad, void* stream);
+
+/* ---------------------------------------------------------------- colour features: DenseGrid.forward for k0
+ * (lib/grid.py:47-58, zeros padding), BARF positional encoding of xyz and view (voxurf_coarse.py:721-732,
+ * :1009-1025), normal (:1028-1030) -> feat[M,64] (57 used, zero padded).  k0 is stored channels-last
+ * [X,Y,Z,C].  pe_w[pos_pe + view_pe] are the c2f weights for this step. */
+int pp_color_feat_fwd(const pp_scene* sc, const float* k0_cl, const float* pts, const float* viewdirs,
+                      const int32_t* ray_id, const float* gradient, const float* pe_w, const int32_t* count,
+                      int32_t capacity, float* feat, void* stream);
+/* feat_grad[M,64] -> k0_grad_cl (atomic +=), pts_grad[M,3] (=), gradient_grad[M,3] (=),
+ * viewdir_grad_s[M,3] (=). */
+int pp_color_feat_bwd(const pp_scene* sc, const float* k0_cl, const float* pts, const float* viewdirs,
+                      const int32_t* ray_id, const float* gradient, const float* pe_w, const int32_t* count,
+                      int32_t capacity, const float* feat_grad, float* k0_grad_cl, float* pts_grad,
+                      float* gradient_grad, float* viewdir_grad_s, void* stream);
+
+/* ---------------------------------------------------------------- MLPs on the matrix cores (fp32 MFMA).
+ * rgbnet (voxurf_coarse.py:208-216, :1032-1033): 64(57)->128->128->128->3, sigmoid.
+ * Parameter block layout (floats): W0[128*64] b0[128] W1[128*128] b1[128] W2[128*128] b2[128] W3[3*128] b3[3]
+ * (W0 is the reference's [128,57] weight zero-padded to 64 columns).
+ * acts[3][cap][128] keeps the hidden activations for the backward. */
+#define PP_RGBNET_PARAMS (128 * 64 + 128 + 2 * (128 * 128 + 128) + 3 * 128 + 3)
+int pp_rgbnet_fwd(const float* params, const float* feat, const int32_t* count, int32_t capacity, float* acts,
+                  float* rgb, void* stream);
+int pp_rgbnet_bwd(const float* params, const float* feat, const float* acts, const float* rgb,
+                  const float* rgb_grad, const int32_t* count, int32_t capacity, float* scratch /*[2][cap][128]*/,
+                  float* params_grad /*atomic +=*/, float* feat_grad, void* stream);
+
+/* warp MLP (DeformedImplicitField, lib/deformation/deform_net.py:12-31, modules.py:43-124): 3->128x4->4 ReLU,
+ * evaluated together with its input Jacobian in forward mode (row 0 primal, rows 1-3 tangents), which
+ * replaces the reference's three autograd.grad(create_graph=True) passes (voxurf_coarse.py:972-984).
+ * Parameter block: W0[128*3] b0[128] W1..W3[128*128]+b[128] each, W4[4*128] b4[4].
+ * acts[4][cap*4][128]; out[M,4,4] (x out_range). */
+#define PP_WARP_PARAMS (128 * 3 + 128 + 3 * (128 * 128 + 128) + 4 * 128 + 4)
+int pp_warp_fwd(const float* params, const float* pts, const int32_t* count, int32_t capacity, float out_range,
+                float* acts, float* out, void* stream);
+int pp_warp_bwd(const float* params, const float* pts, const float* acts, const float* out_grad,
+                const int32_t* count, int32_t capacity, float out_range, float* scratch /*[2][cap*4][128]*/,
+                float* params_grad /*atomic +=*/, float* pts_grad /* += */, void* stream);
+
+/* ---------------------------------------------------------------- losses: lib/losses.py:6-74 (object_losses),
+ * forward values + gradients w.r.t. the render outputs in one pass.  loss_scale multiplies every gradient
+ * (recon_scene.py:648 scales the object loss by 0.1).
+ * loss_out[8] (atomic +=, caller zeroes): [0] mse, [1] entropy, [2] eikonal, [3] grad_deform, [4] sdf_correct,
+ * [5] sdf_deform, [6] bce mask, [7] unused (unweighted scalars, as loss_scalars in the reference).
+ * mask_sum[1] is device scratch.  g_rgb_marched is w.r.t. the CLAMPED rgb_marched (pp_march_bwd applies the
+ * clamp mask). */
+int pp_loss_rays(const float* rgb_marched, const float* alphainv_last, const float* cum_weights,
+                 const float* target, const float* mask_px, float* mask_sum, int32_t n_rays, float w_main,
+                 float w_entropy, float w_mask, float loss_scale, float* g_rgb_marched, float* g_alphainv_last,
+                 float* g_cum_weights, float* loss_out, void* stream);
+/* g_gradient[M,3] is ACCUMULATED (+=); g_grad_deform[M,9], g_correction[M], g_sdf_deform[M] are written. */
+int pp_loss_samples(const float* gradient, const float* grad_deform, const float* warp_out,
+                    const float* sdf_deform, const int32_t* count, int32_t capacity, float w_eikonal,
+                    float w_deform, float loss_scale, float* g_gradient, float* g_grad_deform,
+                    float* g_correction, float* g_sdf_deform, float* loss_out, void* stream);
+
+/* ---------------------------------------------------------------- optimiser: lib/utils.py:82-198 (Adam, betas
+ * (0.9,0.99)) fused with the k0 total-variation gradient (voxurf_coarse.py:443-456, :1298-1313; weight
+ * tv_scale = loss_scale*weight_tv_k0/(3*numel)) and the gradient zero-fill, one streaming pass over the
+ * channels-last grid.  Ping-pong parameter buffers (p_in read incl. neighbours, p_out written).
+ * x-slab [x_begin,x_end) only (ZeRO-1 sharding across ranks); tv_out[1] += sum |diff| of the slab. */
+int pp_grid_tv_adam_step(const float* p_in, float* p_out, float* grad, float* exp_avg, float* exp_avg_sq,
+                         int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, int32_t x_begin,
+                         int32_t x_end, float tv_scale, float grad_scale, float lr, float beta1, float beta2,
+                         float eps, int32_t step, float* tv_out, void* stream);
+/* Flat Adam over a packed parameter buffer with per-segment learning rates: seg_end[n_seg], seg_lr[n_seg]. */
+int pp_adam_flat(float* p, float* grad, float* exp_avg, float* exp_avg_sq, int32_t n, const int32_t* seg_end,
+                 const float* seg_lr, int32_t n_seg, float grad_scale, float beta1, float beta2, float eps,
+                 int32_t step, int32_t zero_grad, void* stream);
+/* total_variation(v) value only (voxurf_coarse.py:1298-1313) on a channels-last grid: out[1] += sum|diff|. */
+int pp_grid_tv_value(const float* p, int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, float* out,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSEPROBE_HIP_H */

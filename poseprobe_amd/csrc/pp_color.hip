@@ -1,0 +1,264 @@
+// Colour-feature stage: k0 feature lookup (DenseGrid.forward, lib/grid.py:47-58, zeros padding), BARF positional
+// encodings (lib/voxurf_coarse.py:721-732, :1009-1025) and the normal feature (:1028-1030), fused into one
+// [M,64] operand for the rgbnet GEMM.  k0 lives channels-last [X,Y,Z,C]: each stencil corner is one contiguous
+// C*4-byte read (3 x 16 B for C=12) instead of C strided 4-byte reads of the reference's [1,C,X,Y,Z] layout.
+#include "pp_common.h"
+
+#define PP_FEAT_LD 64
+
+struct K0Tri {
+  float w0[3], w1[3];
+  int i0[3];
+  bool ok1[3];  // +1 corner inside the grid (zeros padding otherwise)
+  bool ok0[3];
+};
+
+__device__ __forceinline__ void k0_setup(const SceneDev& sc, const float p[3], K0Tri& t) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float u = pp_grid_u(p[a], sc.mn[a], sc.mx[a], sc.sz[a]);
+    float f = floorf(u);
+    t.w1[a] = pp_sub(u, f);
+    t.w0[a] = pp_sub(pp_add(f, 1.f), u);
+    float fc = fminf(fmaxf(f, -2.f), (float)sc.sz[a]);
+    int i = (int)fc;
+    t.i0[a] = i;
+    t.ok0[a] = (i >= 0) && (i < sc.sz[a]);
+    t.ok1[a] = (i + 1 >= 0) && (i + 1 < sc.sz[a]);
+  }
+}
+
+__device__ __forceinline__ bool k0_corner(const SceneDev& sc, const K0Tri& t, int c, size_t& off, float& w) {
+  bool ok = ((c & 4) ? t.ok1[0] : t.ok0[0]) && ((c & 2) ? t.ok1[1] : t.ok0[1]) && ((c & 1) ? t.ok1[2] : t.ok0[2]);
+  int ix = t.i0[0] + ((c >> 2) & 1), iy = t.i0[1] + ((c >> 1) & 1), iz = t.i0[2] + (c & 1);
+  off = (((size_t)ix * sc.sz[1] + iy) * sc.sz[2] + iz) * (size_t)sc.C;
+  w = ((c & 4) ? t.w1[0] : t.w0[0]) * ((c & 2) ? t.w1[1] : t.w0[1]) * ((c & 1) ? t.w1[2] : t.w0[2]);
+  return ok;
+}
+
+__device__ __forceinline__ float pp_norm3c(float x, float y, float z) { return sqrtf(fmaf(z, z, fmaf(y, y, x * x))); }
+
+template <int TC, int TLP, int TLV>
+__global__ __launch_bounds__(256) void k_color_feat_fwd(SceneDev sc, const float* __restrict__ k0,
+                                                        const float* __restrict__ pts, const float* __restrict__ viewdirs,
+                                                        const int32_t* __restrict__ ray_id,
+                                                        const float* __restrict__ gradient, const float* __restrict__ pe_w,
+                                                        const int32_t* __restrict__ count, int capacity,
+                                                        float* __restrict__ feat) {
+  int m = blockIdx.x * blockDim.x + threadIdx.x;
+  int M = min(count[0], capacity);
+  if (m >= M) return;
+  float f[PP_FEAT_LD];
+#pragma unroll
+  for (int i = 0; i < PP_FEAT_LD; ++i) f[i] = 0.f;
+  float p[3] = {pts[m * 3], pts[m * 3 + 1], pts[m * 3 + 2]};
+  K0Tri t;
+  k0_setup(sc, p, t);
+  const int C = TC ? TC : sc.C;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    size_t off; float w;
+    if (k0_corner(sc, t, c, off, w)) {
+      const float4* src = reinterpret_cast<const float4*>(k0 + off);
+#pragma unroll
+      for (int q = 0; q < C / 4; ++q) {
+        float4 v = src[q];
+        f[q * 4 + 0] += v.x * w; f[q * 4 + 1] += v.y * w; f[q * 4 + 2] += v.z * w; f[q * 4 + 3] += v.w * w;
+      }
+    }
+  }
+  int o = C;
+  const int Lp = TLP ? TLP : sc.Lp, Lv = TLV ? TLV : sc.Lv;
+  // xyz embedding: [t(3) | w_k sin(2^k t_a) (a major, k minor) | w_k cos(...)]
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float ta = pp_div(pp_sub(p[a], sc.mn[a]), pp_sub(sc.mx[a], sc.mn[a]));
+    f[o + a] = ta;
+    float fr = 1.f;
+#pragma unroll
+    for (int k = 0; k < Lp; ++k) {
+      float ang = ta * fr, s, c;
+      sincosf(ang, &s, &c);
+      f[o + 3 + a * Lp + k] = s * pe_w[k];
+      f[o + 3 + 3 * Lp + a * Lp + k] = c * pe_w[k];
+      fr *= 2.f;
+    }
+  }
+  o += 3 + 6 * Lp;
+  int r = ray_id[m];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float va = viewdirs[r * 3 + a];
+    f[o + a] = va;
+    float fr = 1.f;
+#pragma unroll
+    for (int k = 0; k < Lv; ++k) {
+      float ang = va * fr, s, c;
+      sincosf(ang, &s, &c);
+      f[o + 3 + a * Lv + k] = s * pe_w[Lp + k];
+      f[o + 3 + 3 * Lv + a * Lv + k] = c * pe_w[Lp + k];
+      fr *= 2.f;
+    }
+  }
+  o += 3 + 6 * Lv;
+  float g[3] = {gradient[m * 3], gradient[m * 3 + 1], gradient[m * 3 + 2]};
+  float gn = pp_norm3c(g[0], g[1], g[2]) + 1e-5f;
+  for (int a = 0; a < 3; ++a) f[o + a] = g[a] / gn;
+  float4* dst = reinterpret_cast<float4*>(feat + (size_t)m * PP_FEAT_LD);
+#pragma unroll
+  for (int q = 0; q < PP_FEAT_LD / 4; ++q) dst[q] = make_float4(f[q * 4], f[q * 4 + 1], f[q * 4 + 2], f[q * 4 + 3]);
+}
+
+// backward, part 1 (thread per sample): everything except the k0 scatter
+template <int TC, int TLP, int TLV>
+__global__ __launch_bounds__(256) void k_color_feat_bwd(SceneDev sc, const float* __restrict__ k0,
+                                                        const float* __restrict__ pts, const float* __restrict__ viewdirs,
+                                                        const int32_t* __restrict__ ray_id,
+                                                        const float* __restrict__ gradient, const float* __restrict__ pe_w,
+                                                        const int32_t* __restrict__ count, int capacity,
+                                                        const float* __restrict__ feat_grad, float* __restrict__ pts_grad,
+                                                        float* __restrict__ gradient_grad, float* __restrict__ vgrad_s) {
+  int m = blockIdx.x * blockDim.x + threadIdx.x;
+  int M = min(count[0], capacity);
+  if (m >= M) return;
+  float fg[PP_FEAT_LD];
+  const float4* src4 = reinterpret_cast<const float4*>(feat_grad + (size_t)m * PP_FEAT_LD);
+#pragma unroll
+  for (int q = 0; q < PP_FEAT_LD / 4; ++q) { float4 v = src4[q]; fg[q * 4] = v.x; fg[q * 4 + 1] = v.y; fg[q * 4 + 2] = v.z; fg[q * 4 + 3] = v.w; }
+  float p[3] = {pts[m * 3], pts[m * 3 + 1], pts[m * 3 + 2]};
+  K0Tri t;
+  k0_setup(sc, p, t);
+  const int C = TC ? TC : sc.C;
+  float pb[3] = {0, 0, 0};
+  // d(k0 feature)/dp : sum_c (K_c . fg) * d w_c / du * scale
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    size_t off; float w;
+    if (k0_corner(sc, t, c, off, w)) {
+      const float4* src = reinterpret_cast<const float4*>(k0 + off);
+      float dot = 0.f;
+#pragma unroll
+      for (int q = 0; q < C / 4; ++q) {
+        float4 v = src[q];
+        dot += v.x * fg[q * 4] + v.y * fg[q * 4 + 1] + v.z * fg[q * 4 + 2] + v.w * fg[q * 4 + 3];
+      }
+      float sx = (c & 4) ? 1.f : -1.f, sy = (c & 2) ? 1.f : -1.f, sz = (c & 1) ? 1.f : -1.f;
+      float wx = (c & 4) ? t.w1[0] : t.w0[0], wy = (c & 2) ? t.w1[1] : t.w0[1], wz = (c & 1) ? t.w1[2] : t.w0[2];
+      pb[0] += dot * sx * wy * wz;
+      pb[1] += dot * wx * sy * wz;
+      pb[2] += dot * wx * wy * sz;
+    }
+  }
+  for (int a = 0; a < 3; ++a) pb[a] *= (float)(sc.sz[a] - 1) / (sc.mx[a] - sc.mn[a]);
+  int o = C;
+  const int Lp = TLP ? TLP : sc.Lp, Lv = TLV ? TLV : sc.Lv;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float ext = pp_sub(sc.mx[a], sc.mn[a]);
+    float ta = pp_div(pp_sub(p[a], sc.mn[a]), ext);
+    float tb = fg[o + a];
+    float fr = 1.f;
+#pragma unroll
+    for (int k = 0; k < Lp; ++k) {
+      float ang = ta * fr, s, c;
+      sincosf(ang, &s, &c);
+      tb += pe_w[k] * fr * (c * fg[o + 3 + a * Lp + k] - s * fg[o + 3 + 3 * Lp + a * Lp + k]);
+      fr *= 2.f;
+    }
+    pb[a] += tb / ext;
+  }
+  o += 3 + 6 * Lp;
+  int r = ray_id[m];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float va = viewdirs[r * 3 + a];
+    float vb = fg[o + a];
+    float fr = 1.f;
+#pragma unroll
+    for (int k = 0; k < Lv; ++k) {
+      float ang = va * fr, s, c;
+      sincosf(ang, &s, &c);
+      vb += pe_w[Lp + k] * fr * (c * fg[o + 3 + a * Lv + k] - s * fg[o + 3 + 3 * Lv + a * Lv + k]);
+      fr *= 2.f;
+    }
+    vgrad_s[m * 3 + a] = vb;
+  }
+  o += 3 + 6 * Lv;
+  float g[3] = {gradient[m * 3], gradient[m * 3 + 1], gradient[m * 3 + 2]};
+  float gn = pp_norm3c(g[0], g[1], g[2]);
+  float gne = gn + 1e-5f;
+  float nb[3] = {fg[o], fg[o + 1], fg[o + 2]};
+  float dot = nb[0] * g[0] + nb[1] * g[1] + nb[2] * g[2];
+  for (int a = 0; a < 3; ++a) {
+    float gb = nb[a] / gne;
+    if (gn > 0.f) gb -= g[a] * dot / (gn * gne * gne);
+    gradient_grad[m * 3 + a] = gb;
+    pts_grad[m * 3 + a] = pb[a];
+  }
+}
+
+// backward, part 2: k0 gradient scatter.  16 lanes per sample, lane = channel: every atomic wave-instruction
+// carries 4 contiguous C*4-byte segments instead of 64 scattered dwords (MI355X float atomics execute at the memory
+// side in 64-B requests; one lane per row is ~17x slower - guide 'Global float atomics').
+__global__ __launch_bounds__(256) void k_k0_scatter(SceneDev sc, const float* __restrict__ pts,
+                                                    const int32_t* __restrict__ count, int capacity,
+                                                    const float* __restrict__ feat_grad, float* __restrict__ k0_grad) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int m = t >> 4, ch = t & 15;
+  int M = min(count[0], capacity);
+  if (m >= M || ch >= sc.C) return;
+  float p[3] = {pts[m * 3], pts[m * 3 + 1], pts[m * 3 + 2]};
+  K0Tri tr;
+  k0_setup(sc, p, tr);
+  float g = feat_grad[(size_t)m * PP_FEAT_LD + ch];
+  if (g == 0.f) return;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    size_t off; float w;
+    if (k0_corner(sc, tr, c, off, w)) atomicAdd(&k0_grad[off + ch], w * g);
+  }
+}
+
+extern "C" int pp_color_feat_fwd(const pp_scene* sc, const float* k0_cl, const float* pts, const float* viewdirs,
+                                 const int32_t* ray_id, const float* gradient, const float* pe_w,
+                                 const int32_t* count, int32_t capacity, float* feat, void* stream) {
+  PP_REQUIRE(sc && k0_cl && pts && viewdirs && ray_id && gradient && pe_w && count && feat, "null pointer");
+  PP_REQUIRE(capacity > 0, "capacity<=0");
+  PP_REQUIRE(sc->k0_dim % 4 == 0 && sc->k0_dim <= 16, "k0_dim must be a multiple of 4 and <= 16");
+  PP_REQUIRE(sc->k0_dim + 3 + 6 * sc->pos_pe + 3 + 6 * sc->view_pe + 3 <= PP_FEAT_LD, "feature width exceeds 64");
+  if (sc->k0_dim == 12 && sc->pos_pe == 5 && sc->view_pe == 1)
+    hipLaunchKernelGGL((k_color_feat_fwd<12, 5, 1>), dim3(pp_div_up(capacity, 256)), dim3(256), 0, pp_stream(stream),
+                       pp_scene_dev(sc), k0_cl, pts, viewdirs, ray_id, gradient, pe_w, count, capacity, feat);
+  else
+    hipLaunchKernelGGL((k_color_feat_fwd<0, 0, 0>), dim3(pp_div_up(capacity, 256)), dim3(256), 0, pp_stream(stream),
+                       pp_scene_dev(sc), k0_cl, pts, viewdirs, ray_id, gradient, pe_w, count, capacity, feat);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_color_feat_bwd(const pp_scene* sc, const float* k0_cl, const float* pts, const float* viewdirs,
+                                 const int32_t* ray_id, const float* gradient, const float* pe_w,
+                                 const int32_t* count, int32_t capacity, const float* feat_grad, float* k0_grad_cl,
+                                 float* pts_grad, float* gradient_grad, float* viewdir_grad_s, void* stream) {
+  PP_REQUIRE(sc && k0_cl && pts && viewdirs && ray_id && gradient && pe_w && count && feat_grad && pts_grad &&
+                 gradient_grad && viewdir_grad_s,
+             "null pointer");
+  PP_REQUIRE(capacity > 0, "capacity<=0");
+  PP_REQUIRE(sc->k0_dim % 4 == 0 && sc->k0_dim <= 16, "k0_dim must be a multiple of 4 and <= 16");
+  hipStream_t st = pp_stream(stream);
+  if (sc->k0_dim == 12 && sc->pos_pe == 5 && sc->view_pe == 1)
+    hipLaunchKernelGGL((k_color_feat_bwd<12, 5, 1>), dim3(pp_div_up(capacity, 256)), dim3(256), 0, st, pp_scene_dev(sc),
+                       k0_cl, pts, viewdirs, ray_id, gradient, pe_w, count, capacity, feat_grad, pts_grad,
+                       gradient_grad, viewdir_grad_s);
+  else
+    hipLaunchKernelGGL((k_color_feat_bwd<0, 0, 0>), dim3(pp_div_up(capacity, 256)), dim3(256), 0, st, pp_scene_dev(sc),
+                       k0_cl, pts, viewdirs, ray_id, gradient, pe_w, count, capacity, feat_grad, pts_grad,
+                       gradient_grad, viewdir_grad_s);
+  PP_CHECK_LAUNCH();
+  if (k0_grad_cl) {
+    hipLaunchKernelGGL(k_k0_scatter, dim3(pp_div_up(capacity * 16, 256)), dim3(256), 0, st, pp_scene_dev(sc), pts, count,
+                       capacity, feat_grad, k0_grad_cl);
+    PP_CHECK_LAUNCH();
+  }
+  return PP_OK;
+}

@@ -1,0 +1,84 @@
+// Shared device/host helpers for libposeprobe_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/poseprobe_hip.h"
+
+#define PP_WAVE 64
+
+void pp_set_error(const char* fmt, ...);
+
+#define PP_REQUIRE(cond, msg)                                     \
+  do {                                                            \
+    if (!(cond)) {                                                \
+      pp_set_error("%s: %s", __func__, msg);                      \
+      return PP_ERR_INVALID_ARG;                                  \
+    }                                                             \
+  } while (0)
+
+#define PP_CHECK_LAUNCH()                                                           \
+  do {                                                                              \
+    hipError_t e__ = hipGetLastError();                                             \
+    if (e__ != hipSuccess) {                                                        \
+      pp_set_error("%s: kernel launch failed: %s", __func__, hipGetErrorString(e__)); \
+      return PP_ERR_LAUNCH;                                                         \
+    }                                                                               \
+  } while (0)
+
+static inline hipStream_t pp_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int pp_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// Scene constants passed by value to kernels (kernarg), derived once on the host.
+struct SceneDev {
+  float mn[3], mx[3];
+  int sz[3];
+  float voxel, stepsize, near_, far_, bg;
+  int S;
+  float out_range;
+  int C, Lp, Lv;
+};
+
+static inline SceneDev pp_scene_dev(const pp_scene* s) {
+  SceneDev d;
+  for (int i = 0; i < 3; ++i) { d.mn[i] = s->xyz_min[i]; d.mx[i] = s->xyz_max[i]; d.sz[i] = s->size[i]; }
+  d.voxel = s->voxel_size; d.stepsize = s->stepsize; d.near_ = s->near_clip; d.far_ = s->far_clip; d.bg = s->bg;
+  d.S = s->n_samples; d.out_range = s->out_range; d.C = s->k0_dim; d.Lp = s->pos_pe; d.Lv = s->view_pe;
+  return d;
+}
+
+#ifdef __HIPCC__
+// exact-rounding primitives: the library is built with -ffp-contract=off, these document intent where the
+// op order of the reference must be reproduced bit for bit (sampler / coordinate transforms).
+__device__ __forceinline__ float pp_mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float pp_add(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float pp_sub(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float pp_div(float a, float b) { return __fdiv_rn(a, b); }
+
+__device__ __forceinline__ float pp_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// softplus(beta=10, threshold=20) as torch.nn.Softplus
+__device__ __forceinline__ float pp_softplus10(float x) {
+  float bx = 10.0f * x;
+  return bx > 20.0f ? x : log1pf(expf(bx)) / 10.0f;
+}
+__device__ __forceinline__ float pp_dsoftplus10(float x) {
+  float bx = 10.0f * x;
+  return bx > 20.0f ? 1.0f : pp_sigmoid(bx);
+}
+
+__device__ __forceinline__ float pp_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// world -> continuous voxel coordinate along one axis, op order of grid_sampler + grid_sample_3d
+// (lib/voxurf_coarse.py:528, :553-555): t=(p-min)/(max-min); n=t*2-1; u=((n+1)/2)*(size-1)
+__device__ __forceinline__ float pp_grid_u(float p, float mn, float mx, int size) {
+  float t = pp_div(pp_sub(p, mn), pp_sub(mx, mn));
+  float n = pp_sub(pp_mul(t, 2.0f), 1.0f);
+  return pp_mul(pp_div(pp_add(n, 1.0f), 2.0f), (float)(size - 1));
+}
+#endif

@@ -1,0 +1,174 @@
+// Transmittance scan (alpha -> weights) and fused compositing, forward and backward.
+// One wavefront per ray: lanes hold 64 consecutive samples (coalesced), the running transmittance is advanced in
+// the reference's *sequential* order inside the wave (v_readlane broadcast), so the 1e-3 early stop and every
+// rounding of lib/cuda/render_utils_kernel.cu:577-605 / :654-707 are reproduced exactly while memory traffic is
+// coalesced (the reference walks each ray from a single thread).
+#include "pp_common.h"
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_march_fwd(const float* __restrict__ alpha, const float* __restrict__ rgb,
+                                                   const float* __restrict__ step_w, const float* __restrict__ nrm_in,
+                                                   const int32_t* __restrict__ ray_start, int n_rays, float bg,
+                                                   float* __restrict__ weights, float* __restrict__ Tout,
+                                                   float* __restrict__ alphainv_last, int32_t* __restrict__ i_end,
+                                                   float* __restrict__ rgb_marched, float* __restrict__ rgb_pre,
+                                                   float* __restrict__ cum_weights, float* __restrict__ depth_acc,
+                                                   float* __restrict__ normal_marched) {
+  int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (r >= n_rays) return;
+  const int b = ray_start[r], e = ray_start[r + 1];
+  float Tc = 1.f;
+  int stop = e;            // absolute index one past the last sample that received a weight
+  bool stopped = false;
+  float acc_rgb[3] = {0, 0, 0}, acc_w = 0.f, acc_d = 0.f, acc_n[3] = {0, 0, 0};
+  for (int c0 = b; c0 < e; c0 += 64) {
+    int i = c0 + lane;
+    float a = (i < e) ? alpha[i] : 0.f;
+    float myT = 1.f, myw = 0.f;
+    if (!stopped) {
+      int n = e - c0 < 64 ? e - c0 : 64;
+      for (int j = 0; j < n; ++j) {
+        float aj = __shfl(a, j, 64);
+        if (lane == j) { myT = Tc; myw = Tc * aj; }
+        Tc = (float)((double)Tc * (1.0 - (double)aj));
+        if ((double)Tc < 1e-3) { stop = c0 + j + 1; stopped = true; break; }
+      }
+    }
+    if (i < e) {
+      weights[i] = myw;
+      if (Tout) Tout[i] = myT;
+      if (FUSED) {
+        acc_w += myw;
+        if (rgb) for (int k = 0; k < 3; ++k) acc_rgb[k] += myw * rgb[i * 3 + k];
+        if (step_w) acc_d += myw * step_w[i];
+        if (nrm_in) for (int k = 0; k < 3; ++k) acc_n[k] += myw * nrm_in[i * 3 + k];
+      }
+    }
+  }
+  if (FUSED) {
+    acc_w = pp_wave_sum(acc_w);
+    acc_d = pp_wave_sum(acc_d);
+    for (int k = 0; k < 3; ++k) { acc_rgb[k] = pp_wave_sum(acc_rgb[k]); acc_n[k] = pp_wave_sum(acc_n[k]); }
+  }
+  if (lane == 0) {
+    alphainv_last[r] = Tc;
+    i_end[r] = stop;
+    if (FUSED) {
+      cum_weights[r] = acc_w;
+      if (depth_acc) depth_acc[r] = acc_d;
+      for (int k = 0; k < 3; ++k) {
+        float pre = acc_rgb[k] + (1.f - acc_w) * bg;
+        if (rgb_pre) rgb_pre[r * 3 + k] = pre;
+        if (rgb_marched) rgb_marched[r * 3 + k] = fminf(fmaxf(pre, 0.f), 1.f);
+        if (normal_marched) normal_marched[r * 3 + k] = acc_n[k];
+      }
+    }
+  }
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_march_bwd(const float* __restrict__ alpha, const float* __restrict__ rgb,
+                                                   const float* __restrict__ step_w, const float* __restrict__ weights,
+                                                   const float* __restrict__ Tin, const float* __restrict__ alphainv_last,
+                                                   const int32_t* __restrict__ ray_start, const int32_t* __restrict__ i_end,
+                                                   int n_rays, float bg, const float* __restrict__ rgb_pre,
+                                                   const float* __restrict__ g_rgbm, const float* __restrict__ g_cw,
+                                                   const float* __restrict__ g_last, const float* __restrict__ g_depth,
+                                                   const float* __restrict__ g_w_in, float* __restrict__ g_alpha,
+                                                   float* __restrict__ g_rgb) {
+  int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (r >= n_rays) return;
+  const int b = ray_start[r], e = ray_start[r + 1], stop = i_end[r];
+  float gm[3] = {0, 0, 0}, gcw = 0.f, gd = 0.f;
+  if (FUSED) {
+    for (int k = 0; k < 3; ++k) {
+      float pre = rgb_pre ? rgb_pre[r * 3 + k] : 0.5f;
+      float g = g_rgbm ? g_rgbm[r * 3 + k] : 0.f;
+      gm[k] = (pre >= 0.f && pre <= 1.f) ? g : 0.f;
+    }
+    gcw = (g_cw ? g_cw[r] : 0.f) - bg * (gm[0] + gm[1] + gm[2]);
+    gd = g_depth ? g_depth[r] : 0.f;
+  }
+  float back = (g_last ? g_last[r] : 0.f) * alphainv_last[r];
+  int nchunk = (e - b + 63) / 64;
+  for (int c = nchunk - 1; c >= 0; --c) {
+    int c0 = b + c * 64;
+    int i = c0 + lane;
+    bool live = i < e;
+    float a = live ? alpha[i] : 0.f;
+    float w = live ? weights[i] : 0.f;
+    float T = live ? Tin[i] : 1.f;
+    float gw = (live && g_w_in) ? g_w_in[i] : 0.f;
+    if (FUSED && live) {
+      float wr = 0.f;
+      if (rgb) for (int k = 0; k < 3; ++k) { float v = rgb[i * 3 + k]; wr += gm[k] * v; if (g_rgb) g_rgb[i * 3 + k] = w * gm[k]; }
+      gw += wr + gcw + (step_w ? gd * step_w[i] : 0.f);
+    }
+    float ga = 0.f;
+    int hi = stop - c0;           // samples [c0, stop) of this chunk take part
+    if (hi > 64) hi = 64;
+    for (int j = hi - 1; j >= 0; --j) {
+      float gwj = __shfl(gw, j, 64), aj = __shfl(a, j, 64), wj = __shfl(w, j, 64), Tj = __shfl(T, j, 64);
+      float gwT = gwj * Tj;
+      double denom = (double)(1.f - aj) + 1e-10;
+      float g = (float)((double)gwT - (double)back / denom);
+      if (lane == j) ga = g;
+      back += gwj * wj;
+    }
+    if (live) g_alpha[i] = ga;
+  }
+}
+
+extern "C" int pp_alpha2weight_fwd(const float* alpha, const int32_t* ray_start, int32_t n_rays, float* weights,
+                                   float* T, float* alphainv_last, int32_t* i_end, void* stream) {
+  PP_REQUIRE(alpha && ray_start && weights && T && alphainv_last && i_end, "null pointer");
+  PP_REQUIRE(n_rays > 0, "n_rays<=0");
+  hipLaunchKernelGGL((k_march_fwd<false>), dim3(pp_div_up(n_rays, 4)), dim3(256), 0, pp_stream(stream), alpha, nullptr,
+                     nullptr, nullptr, ray_start, n_rays, 0.f, weights, T, alphainv_last, i_end, nullptr, nullptr,
+                     nullptr, nullptr, nullptr);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_alpha2weight_bwd(const float* alpha, const float* weights, const float* T, const float* alphainv_last,
+                                   const int32_t* ray_start, const int32_t* i_end, int32_t n_rays,
+                                   const float* grad_weights, const float* grad_last, float* grad_alpha, void* stream) {
+  PP_REQUIRE(alpha && weights && T && alphainv_last && ray_start && i_end && grad_weights && grad_last && grad_alpha,
+             "null pointer");
+  PP_REQUIRE(n_rays > 0, "n_rays<=0");
+  hipLaunchKernelGGL((k_march_bwd<false>), dim3(pp_div_up(n_rays, 4)), dim3(256), 0, pp_stream(stream), alpha, nullptr,
+                     nullptr, weights, T, alphainv_last, ray_start, i_end, n_rays, 0.f, nullptr, nullptr, nullptr,
+                     grad_last, nullptr, grad_weights, grad_alpha, nullptr);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_march_fwd(const float* alpha, const float* rgb, const float* step_w, const float* nrm_in,
+                            const int32_t* ray_start, int32_t n_rays, float bg, float* weights, float* T,
+                            float* alphainv_last, int32_t* i_end, float* rgb_marched, float* rgb_pre,
+                            float* cum_weights, float* depth_acc, float* normal_marched, void* stream) {
+  PP_REQUIRE(alpha && rgb && ray_start && weights && T && alphainv_last && i_end && cum_weights, "null pointer");
+  PP_REQUIRE(n_rays > 0, "n_rays<=0");
+  hipLaunchKernelGGL((k_march_fwd<true>), dim3(pp_div_up(n_rays, 4)), dim3(256), 0, pp_stream(stream), alpha, rgb,
+                     step_w, nrm_in, ray_start, n_rays, bg, weights, T, alphainv_last, i_end, rgb_marched, rgb_pre,
+                     cum_weights, depth_acc, normal_marched);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_march_bwd(const float* alpha, const float* rgb, const float* step_w, const float* weights,
+                            const float* T, const float* alphainv_last, const int32_t* ray_start,
+                            const int32_t* i_end, int32_t n_rays, float bg, const float* rgb_pre,
+                            const float* g_rgb_marched, const float* g_cum_weights, const float* g_alphainv_last,
+                            const float* g_depth_acc, const float* g_weights, float* grad_alpha, float* grad_rgb,
+                            void* stream) {
+  PP_REQUIRE(alpha && rgb && weights && T && alphainv_last && ray_start && i_end && grad_alpha, "null pointer");
+  PP_REQUIRE(n_rays > 0, "n_rays<=0");
+  hipLaunchKernelGGL((k_march_bwd<true>), dim3(pp_div_up(n_rays, 4)), dim3(256), 0, pp_stream(stream), alpha, rgb,
+                     step_w, weights, T, alphainv_last, ray_start, i_end, n_rays, bg, rgb_pre, g_rgb_marched,
+                     g_cum_weights, g_alphainv_last, g_depth_acc, g_weights, grad_alpha, grad_rgb);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}

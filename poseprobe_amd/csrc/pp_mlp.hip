@@ -1,0 +1,517 @@
+// The two shallow MLPs of the object branch on the CDNA4 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+//  * rgbnet  64(57)->128->128->128->3 + sigmoid            (lib/voxurf_coarse.py:208-216, :1032-1033)
+//  * warp    3->128->128->128->128->4, ReLU                 (lib/deformation/deform_net.py:12-31, modules.py:43-124)
+//
+// The warp net is evaluated in "4-row" form: for every sample row 0 is the primal activation and rows 1-3 are the
+// forward-mode tangents d/dp_i.  A hidden layer is then ONE GEMM over 4M rows whose epilogue adds the bias to row 0
+// only and applies row 0's ReLU mask to all four rows; the backward of (value + Jacobian) is the same GEMM chain
+// run in reverse with identical masking.  This replaces the reference's four autograd.grad(create_graph=True)
+// passes and their double backward (lib/voxurf_coarse.py:968-984) by plain matrix products.
+//
+// GEMM tiling: work-group = 256 threads = 4 wavefronts (2x2), block tile 128 rows x 128 features, BK = 32,
+// each wavefront owns a 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 VGPRs).  LDS operand tiles are stored
+// [row][k] with an odd row stride (33) so the per-lane A/B fragment reads (lane -> row, half-wave -> k) are
+// bank-conflict free for ds_read_b32.  In the accumulator layout a lane holds ONE feature column and rows
+// (reg&3) + 8*(reg>>2) + 4*(lane>>5): the four rows of a sample are registers 4q..4q+3 of the same lane, so the
+// 4-row masking needs no cross-lane traffic.
+#include "pp_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LDT 33
+enum { MODE_NT = 0, MODE_NN = 1 };
+enum { EPI_RELU = 0, EPI_MASK = 1, EPI_PLAIN = 2 };
+
+// C[r][n] = epi( sum_k A[r][k] * B(n,k) ),  NT: B(n,k) = W[n*ldw + k]   NN: B(n,k) = W[k*ldw + n]
+template <int MODE, int EPI, int COLS>
+__global__ __launch_bounds__(256) void k_gemm128(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                 int ldw, int K, int Nout, const float* __restrict__ bias,
+                                                 const float* __restrict__ Xmask, int ldm, float* __restrict__ C,
+                                                 int ldc, const int32_t* __restrict__ count, int rmul, int rcap) {
+  __shared__ float As[128 * LDT];
+  __shared__ float Bs[128 * LDT];
+  const int R = min(count[0] * rmul, rcap);
+  const int r0 = blockIdx.x * 128;
+  if (r0 >= R) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+
+  for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int e = tid + i * 256;
+      int row = e >> 3, c4 = e & 7;
+      int gr = r0 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < R) v = *reinterpret_cast<const float4*>(A + (size_t)gr * lda + k0 + c4 * 4);
+      float* d = As + row * LDT + c4 * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    if (MODE == MODE_NT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int e = tid + i * 256;
+        int n = e >> 3, c4 = e & 7;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < Nout) v = *reinterpret_cast<const float4*>(W + (size_t)n * ldw + k0 + c4 * 4);
+        float* d = Bs + n * LDT + c4 * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int e = tid + i * 256;
+        int kk = e >> 5, c4 = e & 31;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 * 4 < Nout) v = *reinterpret_cast<const float4*>(W + (size_t)(k0 + kk) * ldw + c4 * 4);
+        *reinterpret_cast<float4*>(Bs + kk * 128 + c4 * 4) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < 32; kk += 2) {
+      const int kidx = kk + lh;
+      float a0 = As[(wr * 64 + l31) * LDT + kidx];
+      float a1 = As[(wr * 64 + 32 + l31) * LDT + kidx];
+      float b0, b1;
+      if (MODE == MODE_NT) {
+        b0 = Bs[(wc * 64 + l31) * LDT + kidx];
+        b1 = Bs[(wc * 64 + 32 + l31) * LDT + kidx];
+      } else {
+        b0 = Bs[kidx * 128 + wc * 64 + l31];
+        b1 = Bs[kidx * 128 + wc * 64 + 32 + l31];
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // epilogue
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int col = wc * 64 + u * 32 + l31;
+      if (col >= Nout) continue;
+      const float bcol = (EPI == EPI_RELU && bias) ? bias[col] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = r0 + wr * 64 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        if (row >= R) continue;
+        float val = acc[t][u][reg];
+        if (EPI == EPI_RELU) {
+          if (COLS == 1) {
+            val = fmaxf(val + bcol, 0.f);
+          } else {
+            const float y0 = acc[t][u][reg & ~3] + bcol;   // primal row of this sample (same lane)
+            const float y = val + (((reg & 3) == 0) ? bcol : 0.f);
+            val = (y0 > 0.f) ? y : 0.f;
+          }
+        } else if (EPI == EPI_MASK) {
+          const int mrow = (COLS == 1) ? row : row - (reg & 3);
+          val = (Xmask[(size_t)mrow * ldm + col] > 0.f) ? val : 0.f;
+        }
+        C[(size_t)row * ldc + col] = val;
+      }
+    }
+  }
+}
+
+// Wbar[n][k] += sum_r Y[r][n] * X[r][k]   (n < 128, k < Kx) ;  bbar[n] += sum_{r % COLS == 0} Y[r][n]
+template <int COLS>
+__global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ Y, const float* __restrict__ X, int ldx,
+                                                 int Kx, float* __restrict__ Wbar, int ldwb, float* __restrict__ bbar,
+                                                 const int32_t* __restrict__ count, int rmul, int rcap,
+                                                 int rows_per_wg) {
+  __shared__ float Ys[32 * 128];
+  __shared__ float Xs[32 * 128];
+  const int R = min(count[0] * rmul, rcap);
+  const int rb = blockIdx.x * rows_per_wg;
+  if (rb >= R) return;
+  const int re = min(rb + rows_per_wg, R);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const bool active = (wc * 64 < Kx);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+  float bsum = 0.f;
+  const int kx4 = Kx >> 2;
+  for (int r0 = rb; r0 < re; r0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int e = tid + i * 256;
+      int rr = e >> 5, c4 = e & 31;
+      int gr = r0 + rr;
+      float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vx = vy;
+      if (gr < re) {
+        vy = *reinterpret_cast<const float4*>(Y + (size_t)gr * 128 + c4 * 4);
+        if (c4 < kx4) vx = *reinterpret_cast<const float4*>(X + (size_t)gr * ldx + c4 * 4);
+      }
+      *reinterpret_cast<float4*>(Ys + rr * 128 + c4 * 4) = vy;
+      *reinterpret_cast<float4*>(Xs + rr * 128 + c4 * 4) = vx;
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll 4
+      for (int kk = 0; kk < 32; kk += 2) {
+        const int ridx = kk + lh;
+        float a0 = Ys[ridx * 128 + wr * 64 + l31];
+        float a1 = Ys[ridx * 128 + wr * 64 + 32 + l31];
+        float b0 = Xs[ridx * 128 + wc * 64 + l31];
+        float b1 = Xs[ridx * 128 + wc * 64 + 32 + l31];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+    if (tid < 128) {
+#pragma unroll
+      for (int rr = 0; rr < 32; rr += COLS) bsum += Ys[rr * 128 + tid];   // r0 is a multiple of 32 -> rr%COLS==0 rows
+    }
+    __syncthreads();
+  }
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = wc * 64 + u * 32 + l31;
+        if (k >= Kx) continue;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int n = wr * 64 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+          atomicAdd(&Wbar[(size_t)n * ldwb + k], acc[t][u][reg]);
+        }
+      }
+  }
+  if (tid < 128 && bbar) atomicAdd(&bbar[tid], bsum);
+}
+
+// ------------------------------------------------------------------------------------------------ small layers
+// warp layer 0 (3 -> 128) in 4-row form.  block = 2 samples x 128 features.
+__global__ __launch_bounds__(256) void k_warp_l0_fwd(const float* __restrict__ W0, const float* __restrict__ b0,
+                                                     const float* __restrict__ pts, const int32_t* __restrict__ count,
+                                                     int capacity, float* __restrict__ X1) {
+  int M = min(count[0], capacity);
+  int m = blockIdx.x * 2 + (threadIdx.x >> 7), j = threadIdx.x & 127;
+  if (m >= M) return;
+  float w0 = W0[j * 3], w1 = W0[j * 3 + 1], w2 = W0[j * 3 + 2];
+  float y = pts[m * 3] * w0 + pts[m * 3 + 1] * w1 + pts[m * 3 + 2] * w2 + b0[j];
+  bool on = y > 0.f;
+  size_t base = (size_t)m * 4 * 128 + j;
+  X1[base] = on ? y : 0.f;
+  X1[base + 128] = on ? w0 : 0.f;
+  X1[base + 256] = on ? w1 : 0.f;
+  X1[base + 384] = on ? w2 : 0.f;
+}
+
+// warp output layer (128 -> 4) on 4 rows: one wavefront per sample, 16 lanes per row.
+__global__ __launch_bounds__(256) void k_warp_l4_fwd(const float* __restrict__ W4, const float* __restrict__ b4,
+                                                     const float* __restrict__ X4, const int32_t* __restrict__ count,
+                                                     int capacity, float out_range, float* __restrict__ out) {
+  int M = min(count[0], capacity);
+  int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= M) return;
+  int c = lane >> 4, sub = lane & 15;
+  const float4* xp = reinterpret_cast<const float4*>(X4 + ((size_t)m * 4 + c) * 128 + sub * 8);
+  float4 xa = xp[0], xb = xp[1];
+  float acc[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const float4* wp = reinterpret_cast<const float4*>(W4 + o * 128 + sub * 8);
+    float4 wa = wp[0], wb = wp[1];
+    float s = xa.x * wa.x + xa.y * wa.y + xa.z * wa.z + xa.w * wa.w + xb.x * wb.x + xb.y * wb.y + xb.z * wb.z + xb.w * wb.w;
+    s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+    acc[o] = s;
+  }
+  if (sub == 0) {
+    float4 r;
+    r.x = (acc[0] + (c == 0 ? b4[0] : 0.f)) * out_range;
+    r.y = (acc[1] + (c == 0 ? b4[1] : 0.f)) * out_range;
+    r.z = (acc[2] + (c == 0 ? b4[2] : 0.f)) * out_range;
+    r.w = (acc[3] + (c == 0 ? b4[3] : 0.f)) * out_range;
+    *reinterpret_cast<float4*>(out + (size_t)m * 16 + c * 4) = r;
+  }
+}
+
+// backward of the output layer: Ybar4 = mask(X4) * (out_grad*range) W4 ; W4bar, b4bar accumulated over a strip.
+#define STRIP 64
+__global__ __launch_bounds__(256) void k_warp_l4_bwd(const float* __restrict__ W4, const float* __restrict__ X4,
+                                                     const float* __restrict__ out_grad,
+                                                     const int32_t* __restrict__ count, int capacity, float out_range,
+                                                     float* __restrict__ Ybar, float* __restrict__ W4bar,
+                                                     float* __restrict__ b4bar) {
+  __shared__ float red[4 * 128];
+  int M = min(count[0], capacity);
+  int m0 = blockIdx.x * STRIP;
+  if (m0 >= M) return;
+  int h = threadIdx.x >> 7, j = threadIdx.x & 127;
+  float w[4] = {W4[j], W4[128 + j], W4[256 + j], W4[384 + j]};
+  float wacc[4] = {0, 0, 0, 0}, bacc = 0.f;
+  int mend = min(m0 + STRIP, M);
+  for (int m = m0 + h; m < mend; m += 2) {
+    const float* og = out_grad + (size_t)m * 16;
+    size_t base = (size_t)m * 4 * 128 + j;
+    bool on = X4[base] > 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float g0 = og[c * 4] * out_range, g1 = og[c * 4 + 1] * out_range, g2 = og[c * 4 + 2] * out_range,
+            g3 = og[c * 4 + 3] * out_range;
+      float x = X4[base + c * 128];
+      wacc[0] += g0 * x; wacc[1] += g1 * x; wacc[2] += g2 * x; wacc[3] += g3 * x;
+      float xb = g0 * w[0] + g1 * w[1] + g2 * w[2] + g3 * w[3];
+      Ybar[base + c * 128] = on ? xb : 0.f;
+    }
+    if (j < 4) bacc += og[j] * out_range;
+  }
+  if (h == 1) { for (int o = 0; o < 4; ++o) red[o * 128 + j] = wacc[o]; }
+  __syncthreads();
+  if (h == 0) { for (int o = 0; o < 4; ++o) atomicAdd(&W4bar[o * 128 + j], wacc[o] + red[o * 128 + j]); }
+  if (j < 4 && bacc != 0.f) atomicAdd(&b4bar[j], bacc);
+}
+
+// backward of warp layer 0: consumes Ybar1 (already masked), produces W0bar[128,3], b0bar[128], pts_grad += .
+__global__ __launch_bounds__(256) void k_warp_l0_bwd(const float* __restrict__ W0, const float* __restrict__ pts,
+                                                     const float* __restrict__ Ybar, const int32_t* __restrict__ count,
+                                                     int capacity, float* __restrict__ W0bar, float* __restrict__ b0bar,
+                                                     float* __restrict__ pts_grad) {
+  __shared__ float red[4 * 128];
+  __shared__ float pred[4][3];
+  int M = min(count[0], capacity);
+  int m0 = blockIdx.x * STRIP;
+  if (m0 >= M) return;
+  int h = threadIdx.x >> 7, j = threadIdx.x & 127;
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float w[3] = {W0[j * 3], W0[j * 3 + 1], W0[j * 3 + 2]};
+  float wacc[3] = {0, 0, 0}, bacc = 0.f;
+  int mend = min(m0 + STRIP, M);
+  for (int mm = m0; mm < mend; mm += 2) {
+    int m = mm + h;
+    bool live = m < mend;
+    float y0 = 0.f, pb[3] = {0, 0, 0};
+    if (live) {
+      size_t base = (size_t)m * 4 * 128 + j;
+      y0 = Ybar[base];
+      float p0 = pts[m * 3], p1 = pts[m * 3 + 1], p2 = pts[m * 3 + 2];
+      wacc[0] += y0 * p0 + Ybar[base + 128];
+      wacc[1] += y0 * p1 + Ybar[base + 256];
+      wacc[2] += y0 * p2 + Ybar[base + 384];
+      bacc += y0;
+      pb[0] = y0 * w[0]; pb[1] = y0 * w[1]; pb[2] = y0 * w[2];
+    }
+    for (int i = 0; i < 3; ++i) pb[i] = pp_wave_sum(pb[i]);
+    if (lane == 0) { pred[wid][0] = pb[0]; pred[wid][1] = pb[1]; pred[wid][2] = pb[2]; }
+    __syncthreads();
+    if (live && j < 3) pts_grad[m * 3 + j] += pred[h * 2][j] + pred[h * 2 + 1][j];
+    __syncthreads();
+  }
+  if (h == 1) { for (int i = 0; i < 3; ++i) red[i * 128 + j] = wacc[i]; red[3 * 128 + j] = bacc; }
+  __syncthreads();
+  if (h == 0) {
+    for (int i = 0; i < 3; ++i) atomicAdd(&W0bar[j * 3 + i], wacc[i] + red[i * 128 + j]);
+    atomicAdd(&b0bar[j], bacc + red[3 * 128 + j]);
+  }
+}
+
+// rgbnet output layer (128 -> 3) + sigmoid: 16 lanes per sample.
+__global__ __launch_bounds__(256) void k_rgb_out_fwd(const float* __restrict__ W3, const float* __restrict__ b3,
+                                                     const float* __restrict__ H3, const int32_t* __restrict__ count,
+                                                     int capacity, float* __restrict__ rgb) {
+  int M = min(count[0], capacity);
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int m = t >> 4, sub = t & 15;
+  bool live = m < M;
+  float4 xa = make_float4(0, 0, 0, 0), xb = xa;
+  if (live) {
+    const float4* xp = reinterpret_cast<const float4*>(H3 + (size_t)m * 128 + sub * 8);
+    xa = xp[0]; xb = xp[1];
+  }
+  float acc[3];
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    const float4* wp = reinterpret_cast<const float4*>(W3 + o * 128 + sub * 8);
+    float4 wa = wp[0], wb = wp[1];
+    float s = xa.x * wa.x + xa.y * wa.y + xa.z * wa.z + xa.w * wa.w + xb.x * wb.x + xb.y * wb.y + xb.z * wb.z + xb.w * wb.w;
+    s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+    acc[o] = s;
+  }
+  if (live && sub == 0)
+    for (int o = 0; o < 3; ++o) rgb[m * 3 + o] = pp_sigmoid(acc[o] + b3[o]);
+}
+
+__global__ __launch_bounds__(256) void k_rgb_out_bwd(const float* __restrict__ W3, const float* __restrict__ H3,
+                                                     const float* __restrict__ rgb, const float* __restrict__ rgb_grad,
+                                                     const int32_t* __restrict__ count, int capacity,
+                                                     float* __restrict__ Ybar, float* __restrict__ W3bar,
+                                                     float* __restrict__ b3bar) {
+  __shared__ float red[3 * 128];
+  int M = min(count[0], capacity);
+  int m0 = blockIdx.x * STRIP;
+  if (m0 >= M) return;
+  int h = threadIdx.x >> 7, j = threadIdx.x & 127;
+  float w[3] = {W3[j], W3[128 + j], W3[256 + j]};
+  float wacc[3] = {0, 0, 0}, bacc = 0.f;
+  int mend = min(m0 + STRIP, M);
+  for (int m = m0 + h; m < mend; m += 2) {
+    float gl[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) { float r = rgb[m * 3 + o]; gl[o] = rgb_grad[m * 3 + o] * r * (1.f - r); }
+    float x = H3[(size_t)m * 128 + j];
+    wacc[0] += gl[0] * x; wacc[1] += gl[1] * x; wacc[2] += gl[2] * x;
+    float hb = gl[0] * w[0] + gl[1] * w[1] + gl[2] * w[2];
+    Ybar[(size_t)m * 128 + j] = (x > 0.f) ? hb : 0.f;
+    if (j < 3) bacc += gl[j];
+  }
+  if (h == 1) { for (int o = 0; o < 3; ++o) red[o * 128 + j] = wacc[o]; }
+  __syncthreads();
+  if (h == 0) { for (int o = 0; o < 3; ++o) atomicAdd(&W3bar[o * 128 + j], wacc[o] + red[o * 128 + j]); }
+  if (j < 3 && bacc != 0.f) atomicAdd(&b3bar[j], bacc);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+#define RG_W0 0
+#define RG_B0 (128 * 64)
+#define RG_W1 (RG_B0 + 128)
+#define RG_B1 (RG_W1 + 128 * 128)
+#define RG_W2 (RG_B1 + 128)
+#define RG_B2 (RG_W2 + 128 * 128)
+#define RG_W3 (RG_B2 + 128)
+#define RG_B3 (RG_W3 + 3 * 128)
+
+#define WP_W0 0
+#define WP_B0 (128 * 3)
+#define WP_W1 (WP_B0 + 128)
+#define WP_B1 (WP_W1 + 128 * 128)
+#define WP_W2 (WP_B1 + 128)
+#define WP_B2 (WP_W2 + 128 * 128)
+#define WP_W3 (WP_B2 + 128)
+#define WP_B3 (WP_W3 + 128 * 128)
+#define WP_W4 (WP_B3 + 128)
+#define WP_B4 (WP_W4 + 4 * 128)
+
+static const int TN_ROWS = 512;
+
+extern "C" int pp_rgbnet_fwd(const float* params, const float* feat, const int32_t* count, int32_t capacity,
+                             float* acts, float* rgb, void* stream) {
+  PP_REQUIRE(params && feat && count && acts && rgb, "null pointer");
+  PP_REQUIRE(capacity > 0, "capacity<=0");
+  hipStream_t st = pp_stream(stream);
+  const size_t LS = (size_t)capacity * 128;
+  dim3 g(pp_div_up(capacity, 128)), b(256);
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1>), g, b, 0, st, feat, 64, params + RG_W0, 64, 64, 128,
+                     params + RG_B0, nullptr, 0, acts, 128, count, 1, capacity);
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1>), g, b, 0, st, acts, 128, params + RG_W1, 128, 128, 128,
+                     params + RG_B1, nullptr, 0, acts + LS, 128, count, 1, capacity);
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1>), g, b, 0, st, acts + LS, 128, params + RG_W2, 128, 128, 128,
+                     params + RG_B2, nullptr, 0, acts + 2 * LS, 128, count, 1, capacity);
+  hipLaunchKernelGGL(k_rgb_out_fwd, dim3(pp_div_up(capacity * 16, 256)), b, 0, st, params + RG_W3, params + RG_B3,
+                     acts + 2 * LS, count, capacity, rgb);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_rgbnet_bwd(const float* params, const float* feat, const float* acts, const float* rgb,
+                             const float* rgb_grad, const int32_t* count, int32_t capacity, float* scratch,
+                             float* params_grad, float* feat_grad, void* stream) {
+  PP_REQUIRE(params && feat && acts && rgb && rgb_grad && count && scratch && params_grad && feat_grad, "null pointer");
+  PP_REQUIRE(capacity > 0, "capacity<=0");
+  hipStream_t st = pp_stream(stream);
+  const size_t LS = (size_t)capacity * 128;
+  float* s0 = scratch;
+  float* s1 = scratch + LS;
+  dim3 g(pp_div_up(capacity, 128)), gt(pp_div_up(capacity, TN_ROWS)), b(256);
+  hipLaunchKernelGGL(k_rgb_out_bwd, dim3(pp_div_up(capacity, STRIP)), b, 0, st, params + RG_W3, acts + 2 * LS, rgb,
+                     rgb_grad, count, capacity, s0, params_grad + RG_W3, params_grad + RG_B3);
+  // layer 2
+  hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, s0, acts + LS, 128, 128, params_grad + RG_W2, 128,
+                     params_grad + RG_B2, count, 1, capacity, TN_ROWS);
+  hipLaunchKernelGGL((k_gemm128<MODE_NN, EPI_MASK, 1>), g, b, 0, st, s0, 128, params + RG_W2, 128, 128, 128, nullptr,
+                     acts + LS, 128, s1, 128, count, 1, capacity);
+  // layer 1
+  hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, s1, acts, 128, 128, params_grad + RG_W1, 128, params_grad + RG_B1,
+                     count, 1, capacity, TN_ROWS);
+  hipLaunchKernelGGL((k_gemm128<MODE_NN, EPI_MASK, 1>), g, b, 0, st, s1, 128, params + RG_W1, 128, 128, 128, nullptr,
+                     acts, 128, s0, 128, count, 1, capacity);
+  // layer 0
+  hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, s0, feat, 64, 64, params_grad + RG_W0, 64, params_grad + RG_B0,
+                     count, 1, capacity, TN_ROWS);
+  hipLaunchKernelGGL((k_gemm128<MODE_NN, EPI_PLAIN, 1>), g, b, 0, st, s0, 128, params + RG_W0, 64, 128, 64, nullptr,
+                     nullptr, 0, feat_grad, 64, count, 1, capacity);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_warp_fwd(const float* params, const float* pts, const int32_t* count, int32_t capacity,
+                           float out_range, float* acts, float* out, void* stream) {
+  PP_REQUIRE(params && pts && count && acts && out, "null pointer");
+  PP_REQUIRE(capacity > 0, "capacity<=0");
+  hipStream_t st = pp_stream(stream);
+  const int rcap = capacity * 4;
+  const size_t LS = (size_t)rcap * 128;
+  dim3 g(pp_div_up(rcap, 128)), b(256);
+  hipLaunchKernelGGL(k_warp_l0_fwd, dim3(pp_div_up(capacity, 2)), b, 0, st, params + WP_W0, params + WP_B0, pts, count,
+                     capacity, acts);
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 4>), g, b, 0, st, acts, 128, params + WP_W1, 128, 128, 128,
+                     params + WP_B1, nullptr, 0, acts + LS, 128, count, 4, rcap);
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 4>), g, b, 0, st, acts + LS, 128, params + WP_W2, 128, 128, 128,
+                     params + WP_B2, nullptr, 0, acts + 2 * LS, 128, count, 4, rcap);
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 4>), g, b, 0, st, acts + 2 * LS, 128, params + WP_W3, 128, 128, 128,
+                     params + WP_B3, nullptr, 0, acts + 3 * LS, 128, count, 4, rcap);
+  hipLaunchKernelGGL(k_warp_l4_fwd, dim3(pp_div_up(capacity, 4)), b, 0, st, params + WP_W4, params + WP_B4,
+                     acts + 3 * LS, count, capacity, out_range, out);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* acts, const float* out_grad,
+                           const int32_t* count, int32_t capacity, float out_range, float* scratch,
+                           float* params_grad, float* pts_grad, void* stream) {
+  PP_REQUIRE(params && pts && acts && out_grad && count && scratch && params_grad && pts_grad, "null pointer");
+  PP_REQUIRE(capacity > 0, "capacity<=0");
+  hipStream_t st = pp_stream(stream);
+  const int rcap = capacity * 4;
+  const size_t LS = (size_t)rcap * 128;
+  float* s0 = scratch;
+  float* s1 = scratch + LS;
+  dim3 g(pp_div_up(rcap, 128)), gt(pp_div_up(rcap, TN_ROWS)), b(256);
+  hipLaunchKernelGGL(k_warp_l4_bwd, dim3(pp_div_up(capacity, STRIP)), b, 0, st, params + WP_W4, acts + 3 * LS, out_grad,
+                     count, capacity, out_range, s0, params_grad + WP_W4, params_grad + WP_B4);
+  // layer 3
+  hipLaunchKernelGGL((k_gemm_tn<4>), gt, b, 0, st, s0, acts + 2 * LS, 128, 128, params_grad + WP_W3, 128,
+                     params_grad + WP_B3, count, 4, rcap, TN_ROWS);
+  hipLaunchKernelGGL((k_gemm128<MODE_NN, EPI_MASK, 4>), g, b, 0, st, s0, 128, params + WP_W3, 128, 128, 128, nullptr,
+                     acts + 2 * LS, 128, s1, 128, count, 4, rcap);
+  // layer 2
+  hipLaunchKernelGGL((k_gemm_tn<4>), gt, b, 0, st, s1, acts + LS, 128, 128, params_grad + WP_W2, 128,
+                     params_grad + WP_B2, count, 4, rcap, TN_ROWS);
+  hipLaunchKernelGGL((k_gemm128<MODE_NN, EPI_MASK, 4>), g, b, 0, st, s1, 128, params + WP_W2, 128, 128, 128, nullptr,
+                     acts + LS, 128, s0, 128, count, 4, rcap);
+  // layer 1
+  hipLaunchKernelGGL((k_gemm_tn<4>), gt, b, 0, st, s0, acts, 128, 128, params_grad + WP_W1, 128, params_grad + WP_B1,
+                     count, 4, rcap, TN_ROWS);
+  hipLaunchKernelGGL((k_gemm128<MODE_NN, EPI_MASK, 4>), g, b, 0, st, s0, 128, params + WP_W1, 128, 128, 128, nullptr,
+                     acts, 128, s1, 128, count, 4, rcap);
+  // layer 0
+  hipLaunchKernelGGL(k_warp_l0_bwd, dim3(pp_div_up(capacity, STRIP)), b, 0, st, params + WP_W0, pts, s1, count, capacity,
+                     params_grad + WP_W0, params_grad + WP_B0, pts_grad);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}

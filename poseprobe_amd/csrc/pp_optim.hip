@@ -1,0 +1,168 @@
+// Optimiser: the reference's Adam (lib/utils.py:82-198, betas (0.9,0.99) from :342) fused, for the dense k0 grid,
+// with the total-variation gradient (lib/voxurf_coarse.py:443-456, :1298-1313) and the gradient zero-fill into ONE
+// streaming pass: reads p,g,m,v (+ 6 neighbours of p, cache-served), writes p',m,v and g=0 : 384 B/voxel at C=12
+// instead of the reference's separate TV forward, TV backward, zero_grad and Adam passes (528 B/voxel).
+// Parameters ping-pong between two buffers so that neighbour reads never see updated values.
+#include "pp_common.h"
+
+__device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : (x < 0.f ? -1.f : 0.f); }
+__device__ __forceinline__ float4 sgn4(float4 a, float4 b) {
+  return make_float4(sgnf(a.x - b.x), sgnf(a.y - b.y), sgnf(a.z - b.z), sgnf(a.w - b.w));
+}
+__device__ __forceinline__ float abs4(float4 a, float4 b) {
+  return fabsf(a.x - b.x) + fabsf(a.y - b.y) + fabsf(a.z - b.z) + fabsf(a.w - b.w);
+}
+
+__device__ __forceinline__ float adam1(float p, float g, float& m, float& v, float b1, float b2, float eps,
+                                       float step_size, float inv_sqrt_bc2) {
+  m = m * b1 + (1.f - b1) * g;
+  v = v * b2 + (1.f - b2) * g * g;
+  float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+  return p - step_size * (m / denom);
+}
+
+// one thread = one float4 (4 channels of one voxel); q4 = C/4 float4 per voxel
+__global__ __launch_bounds__(256) void k_grid_tv_adam(const float4* __restrict__ p_in, float4* __restrict__ p_out,
+                                                      float4* __restrict__ grad, float4* __restrict__ m_,
+                                                      float4* __restrict__ v_, int X, int Y, int Z, int q4,
+                                                      int x_begin, int x_end, float tv_scale, float grad_scale,
+                                                      float b1, float b2, float eps, float step_size,
+                                                      float inv_sqrt_bc2, float* __restrict__ tv_out) {
+  __shared__ float sm[4];
+  const long long n_slab = (long long)(x_end - x_begin) * Y * Z * q4;
+  // XCD-aware placement: blocks that share an XCD (same blockIdx % 8) sweep one contiguous eighth of the slab, so the
+  // +-x / +-y neighbour planes a block touches were (or will be) streamed through the SAME XCD's L2.
+  const int nb = gridDim.x;
+  const int per = (nb + 7) / 8;
+  const int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  long long e = (long long)bid * 256 + threadIdx.x;
+  float tv_local = 0.f;
+  if (bid < nb && e < n_slab) {
+    e += (long long)x_begin * Y * Z * q4;
+    long long vox = e / q4;
+    int z = (int)(vox % Z);
+    long long t = vox / Z;
+    int y = (int)(t % Y);
+    int x = (int)(t / Y);
+    const long long sz = q4, sy = (long long)Z * q4, sx = (long long)Y * Z * q4;
+    float4 p = p_in[e];
+    float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (z > 0) { float4 s = sgn4(p, p_in[e - sz]); tv.x += s.x; tv.y += s.y; tv.z += s.z; tv.w += s.w; }
+    if (y > 0) { float4 s = sgn4(p, p_in[e - sy]); tv.x += s.x; tv.y += s.y; tv.z += s.z; tv.w += s.w; }
+    if (x > 0) { float4 s = sgn4(p, p_in[e - sx]); tv.x += s.x; tv.y += s.y; tv.z += s.z; tv.w += s.w; }
+    if (z < Z - 1) { float4 nbv = p_in[e + sz]; float4 s = sgn4(p, nbv); tv.x += s.x; tv.y += s.y; tv.z += s.z; tv.w += s.w; tv_local += abs4(p, nbv); }
+    if (y < Y - 1) { float4 nbv = p_in[e + sy]; float4 s = sgn4(p, nbv); tv.x += s.x; tv.y += s.y; tv.z += s.z; tv.w += s.w; tv_local += abs4(p, nbv); }
+    if (x < X - 1) { float4 nbv = p_in[e + sx]; float4 s = sgn4(p, nbv); tv.x += s.x; tv.y += s.y; tv.z += s.z; tv.w += s.w; tv_local += abs4(p, nbv); }
+    float4 g = grad[e], m = m_[e], v = v_[e];
+    g.x = g.x * grad_scale + tv_scale * tv.x; g.y = g.y * grad_scale + tv_scale * tv.y;
+    g.z = g.z * grad_scale + tv_scale * tv.z; g.w = g.w * grad_scale + tv_scale * tv.w;
+    float4 o;
+    o.x = adam1(p.x, g.x, m.x, v.x, b1, b2, eps, step_size, inv_sqrt_bc2);
+    o.y = adam1(p.y, g.y, m.y, v.y, b1, b2, eps, step_size, inv_sqrt_bc2);
+    o.z = adam1(p.z, g.z, m.z, v.z, b1, b2, eps, step_size, inv_sqrt_bc2);
+    o.w = adam1(p.w, g.w, m.w, v.w, b1, b2, eps, step_size, inv_sqrt_bc2);
+    p_out[e] = o;
+    m_[e] = m;
+    v_[e] = v;
+    grad[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (tv_out) {
+    tv_local = pp_wave_sum(tv_local);
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) sm[wid] = tv_local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s = sm[0] + sm[1] + sm[2] + sm[3];
+      if (s != 0.f) atomicAdd(tv_out, s);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_grid_tv_value(const float4* __restrict__ p_in, int X, int Y, int Z, int q4,
+                                                       float* __restrict__ tv_out) {
+  __shared__ float sm[4];
+  const long long n = (long long)X * Y * Z * q4;
+  float tv_local = 0.f;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    long long vox = e / q4;
+    int z = (int)(vox % Z);
+    long long t = vox / Z;
+    int y = (int)(t % Y);
+    int x = (int)(t / Y);
+    float4 p = p_in[e];
+    if (z < Z - 1) tv_local += abs4(p, p_in[e + q4]);
+    if (y < Y - 1) tv_local += abs4(p, p_in[e + (long long)Z * q4]);
+    if (x < X - 1) tv_local += abs4(p, p_in[e + (long long)Y * Z * q4]);
+  }
+  tv_local = pp_wave_sum(tv_local);
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) sm[wid] = tv_local;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(tv_out, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+__global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, float* __restrict__ grad, float* __restrict__ m_,
+                                                   float* __restrict__ v_, int n, const int32_t* __restrict__ seg_end,
+                                                   const float* __restrict__ seg_lr, int n_seg, float grad_scale,
+                                                   float b1, float b2, float eps, float inv_bc1, float inv_sqrt_bc2,
+                                                   int zero_grad) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int s = 0;
+  while (s < n_seg - 1 && i >= seg_end[s]) ++s;
+  float lr = seg_lr[s];
+  float g = grad[i] * grad_scale, m = m_[i], v = v_[i];
+  float o = adam1(p[i], g, m, v, b1, b2, eps, lr * inv_bc1, inv_sqrt_bc2);
+  if (lr != 0.f) p[i] = o;
+  m_[i] = m;
+  v_[i] = v;
+  if (zero_grad) grad[i] = 0.f;
+}
+
+extern "C" int pp_grid_tv_adam_step(const float* p_in, float* p_out, float* grad, float* exp_avg, float* exp_avg_sq,
+                                    int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, int32_t x_begin, int32_t x_end,
+                                    float tv_scale, float grad_scale, float lr, float beta1, float beta2, float eps,
+                                    int32_t step, float* tv_out, void* stream) {
+  PP_REQUIRE(p_in && p_out && grad && exp_avg && exp_avg_sq, "null pointer");
+  const int32_t size[3] = {size_x, size_y, size_z};
+  PP_REQUIRE(p_in != p_out, "p_in and p_out must be distinct (ping-pong) buffers");
+  PP_REQUIRE(channels > 0 && channels % 4 == 0, "channels must be a positive multiple of 4");
+  PP_REQUIRE(0 <= x_begin && x_begin < x_end && x_end <= size[0], "bad x slab");
+  PP_REQUIRE(step >= 1, "step must be >= 1");
+  const int q4 = channels / 4;
+  const long long n = (long long)(x_end - x_begin) * size[1] * size[2] * q4;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  int blocks = (int)((n + 255) / 256);
+  blocks = ((blocks + 7) / 8) * 8;
+  hipLaunchKernelGGL(k_grid_tv_adam, dim3(blocks), dim3(256), 0, pp_stream(stream),
+                     reinterpret_cast<const float4*>(p_in), reinterpret_cast<float4*>(p_out),
+                     reinterpret_cast<float4*>(grad), reinterpret_cast<float4*>(exp_avg),
+                     reinterpret_cast<float4*>(exp_avg_sq), size[0], size[1], size[2], q4, x_begin, x_end, tv_scale,
+                     grad_scale, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), tv_out);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_grid_tv_value(const float* p, int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels,
+                                float* out, void* stream) {
+  PP_REQUIRE(p && out, "null pointer");
+  const int32_t size[3] = {size_x, size_y, size_z};
+  PP_REQUIRE(channels > 0 && channels % 4 == 0, "channels must be a positive multiple of 4");
+  hipLaunchKernelGGL(k_grid_tv_value, dim3(2048), dim3(256), 0, pp_stream(stream), reinterpret_cast<const float4*>(p),
+                     size[0], size[1], size[2], channels / 4, out);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_adam_flat(float* p, float* grad, float* exp_avg, float* exp_avg_sq, int32_t n,
+                            const int32_t* seg_end, const float* seg_lr, int32_t n_seg, float grad_scale, float beta1,
+                            float beta2, float eps, int32_t step, int32_t zero_grad, void* stream) {
+  PP_REQUIRE(p && grad && exp_avg && exp_avg_sq && seg_end && seg_lr, "null pointer");
+  PP_REQUIRE(n > 0 && n_seg > 0 && step >= 1, "bad sizes");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(k_adam_flat, dim3(pp_div_up(n, 256)), dim3(256), 0, pp_stream(stream), p, grad, exp_avg,
+                     exp_avg_sq, n, seg_end, seg_lr, n_seg, grad_scale, beta1, beta2, eps, (float)(1.0 / bc1),
+                     (float)(1.0 / sqrt(bc2)), zero_grad);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}

@@ -1,0 +1,393 @@
+"""Host-side orchestration of the HIP hot path: workspace, forward chain, hand-derived backward chain and
+the fused train step (ray select -> render -> loss -> backward -> optimiser), with zero host syncs.
+
+Mirrors one iteration of the object branch in recon_scene.optimize_increamental
+(lib/recon_scene.py:572-606, :648-649, :742-747, :765-771) and Voxurf.forward (lib/voxurf_coarse.py:922-1092).
+torch is used for device memory and streams only; every arithmetic step is a kernel of libposeprobe_hip.so.
+"""
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import ops
+
+PAD = 64
+
+
+def _pad(n):
+    return (n + PAD - 1) // PAD * PAD
+
+
+@dataclass
+class SceneConfig:
+    xyz_min: np.ndarray
+    xyz_max: np.ndarray
+    num_voxels: int
+    stepsize: float = 1.5
+    near: float = 0.24
+    far: float = 4.8
+    bg: float = 0.0
+    N_iters: int = 10000
+    s_ratio: float = 50.0
+    s_start: float = 0.2
+    step_start: float = 0.0
+    barf_c2f: tuple = (0.6, 1.0)
+    posbase_pe: int = 5
+    viewbase_pe: int = 1
+    k0_dim: int = 12
+    out_range: float = 1.0
+    inverse_y: bool = True
+
+    def __post_init__(self):
+        # identical fp32 arithmetic to Voxurf._set_grid_resolution (voxurf_coarse.py:319-323)
+        lo = torch.tensor(np.asarray(self.xyz_min, dtype=np.float32))
+        hi = torch.tensor(np.asarray(self.xyz_max, dtype=np.float32))
+        vs = ((hi - lo).prod() / self.num_voxels).pow(1 / 3)
+        self.voxel_size = float(vs)
+        self.world_size = [int(v) for v in ((hi - lo) / vs).long().tolist()]
+        self.pp = ops.make_scene(lo.tolist(), hi.tolist(), self.world_size, self.voxel_size, self.stepsize, self.near,
+                                 self.far, self.bg, self.out_range, self.k0_dim, self.posbase_pe, self.viewbase_pe)
+        self.n_samples = self.pp.n_samples
+
+    def s_val(self, global_step):
+        return 1. / (global_step + self.s_ratio / self.s_start - self.step_start) * self.s_ratio
+
+    def pe_weights(self, progress):
+        """BARF c2f weights for xyz (L=posbase_pe) then view (L=viewbase_pe); voxurf_coarse.py:721-732 (fp32 ops)."""
+        out = []
+        for L in (self.posbase_pe, self.viewbase_pe):
+            if self.barf_c2f is None:
+                out.append(np.ones(L, dtype=np.float32))
+                continue
+            start, end = self.barf_c2f
+            alpha = (torch.tensor(progress, dtype=torch.float32) - start) / (end - start) * L
+            k = torch.arange(L, dtype=torch.float32)
+            w = (1 - (alpha - k).clamp_(min=0, max=1).mul_(np.pi).cos_()) / 2
+            out.append(w.numpy())
+        return np.concatenate(out).astype(np.float32)
+
+
+def dynamic_weight(w0, w1, it, total):
+    """lib/losses.py:30-32"""
+    return w0 * math.exp(math.log(w1 / w0) / total * it)
+
+
+class Workspace:
+    """All per-ray / per-sample device buffers for N rays and `capacity` samples (default N*S)."""
+
+    def __init__(self, N, capacity, device):
+        f = dict(dtype=torch.float32, device=device)
+        i = dict(dtype=torch.int32, device=device)
+        self.N, self.cap = N, capacity
+        e = torch.empty
+        # rays
+        self.rays_o, self.rays_d, self.viewdirs = e(N, 3, **f), e(N, 3, **f), e(N, 3, **f)
+        self.target, self.mask_px = e(N, 3, **f), e(N, **f)
+        self.t_min, self.t_max = e(N, **f), e(N, **f)
+        self.ray_start = torch.zeros(N + 1, **i)
+        self.count = torch.zeros(1, **i)
+        # samples
+        self.pts, self.ray_id, self.step_k, self.step = e(capacity, 3, **f), e(capacity, **i), e(capacity, **i), e(capacity, **f)
+        self.warp_acts = e(4, capacity * 4, 128, **f)
+        self.warp_out = e(capacity, 16, **f)
+        self.alpha, self.gradient = e(capacity, **f), e(capacity, 3, **f)
+        self.sdf_final, self.sdf_deform, self.grad_deform = e(capacity, **f), e(capacity, **f), e(capacity, 9, **f)
+        self.feat = e(capacity, ops.FEAT_LD, **f)
+        self.rgb_acts = e(3, capacity, 128, **f)
+        self.rgb = e(capacity, 3, **f)
+        self.weights, self.T = e(capacity, **f), e(capacity, **f)
+        # ray outputs
+        self.alphainv_last, self.i_end = e(N, **f), e(N, **i)
+        self.rgb_marched, self.rgb_pre = e(N, 3, **f), e(N, 3, **f)
+        self.cum_weights, self.depth_acc = e(N, **f), e(N, **f)
+        # backward buffers
+        self.g_rgbm, self.g_last, self.g_cw = e(N, 3, **f), e(N, **f), e(N, **f)
+        self.g_alpha, self.g_rgb = e(capacity, **f), e(capacity, 3, **f)
+        self.g_feat = e(capacity, ops.FEAT_LD, **f)
+        self.g_gradient, self.g_pts, self.g_view_s = e(capacity, 3, **f), e(capacity, 3, **f), e(capacity, 3, **f)
+        self.g_grad_deform, self.g_corr, self.g_sdf_deform = e(capacity, 9, **f), e(capacity, **f), e(capacity, **f)
+        self.g_warp_out = e(capacity, 16, **f)
+        self.scratch = e(2, capacity * 4, 128, **f)     # shared by both MLP backward chains
+        self.mask_sum = torch.zeros(1, **f)
+        self.loss_out = torch.zeros(8, **f)
+        self.tv_out = torch.zeros(1, **f)
+        self.g_rays_o, self.g_rays_d, self.g_viewdirs = e(N, 3, **f), e(N, 3, **f), e(N, 3, **f)
+
+
+class FlatParams:
+    """Packed small parameters: [sdf_ab | rgbnet | warp], each segment padded to 64 floats (16-B aligned sub-blocks)."""
+    SEG = [('sdf_ab', 2), ('rgbnet', ops.RGBNET_PARAMS), ('warp', ops.WARP_PARAMS)]
+
+    def __init__(self, device):
+        self.off, o = {}, 0
+        for name, n in self.SEG:
+            self.off[name] = (o, n)
+            o += _pad(n)
+        self.n = o
+        z = lambda: torch.zeros(o, dtype=torch.float32, device=device)
+        self.data, self.grad, self.m, self.v = z(), z(), z(), z()
+
+    def view(self, name, which='data'):
+        o, n = self.off[name]
+        return getattr(self, which)[o:o + n]
+
+    # ---- conversion from / to the reference's state_dict tensors -------------------------------------------
+    def load_reference(self, sdf_alpha, sdf_beta, rgbnet, warp):
+        """rgbnet: 4 x (W[out,in], b) ; warp: 5 x (W, b) in the reference layouts."""
+        with torch.no_grad():
+            self.view('sdf_ab').copy_(torch.cat([sdf_alpha.reshape(1), sdf_beta.reshape(1)]))
+            self.view('rgbnet').copy_(pack_rgbnet(rgbnet).to(self.data.device))
+            self.view('warp').copy_(pack_warp(warp).to(self.data.device))
+
+    def export_grads(self):
+        g = {'sdf_alpha': self.view('sdf_ab', 'grad')[0:1].clone(), 'sdf_beta': self.view('sdf_ab', 'grad')[1:2].clone()}
+        g['rgbnet'] = unpack_rgbnet(self.view('rgbnet', 'grad'))
+        g['warp'] = unpack_warp(self.view('warp', 'grad'))
+        return g
+
+
+def pack_rgbnet(layers, in_dim=57):
+    W0, b0 = layers[0]
+    W0p = torch.zeros(128, 64, dtype=torch.float32, device=W0.device)
+    W0p[:, :W0.shape[1]] = W0
+    parts = [W0p.reshape(-1), b0]
+    for W, b in layers[1:]:
+        parts += [W.reshape(-1), b]
+    return torch.cat([p.detach().float() for p in parts])
+
+
+def unpack_rgbnet(flat, in_dim=57):
+    o, out = 0, []
+    W0 = flat[o:o + 128 * 64].reshape(128, 64)[:, :in_dim]; o += 128 * 64
+    b0 = flat[o:o + 128]; o += 128
+    out.append((W0, b0))
+    for shp in ((128, 128), (128, 128), (3, 128)):
+        n = shp[0] * shp[1]
+        W = flat[o:o + n].reshape(shp); o += n
+        b = flat[o:o + shp[0]]; o += shp[0]
+        out.append((W, b))
+    return out
+
+
+def pack_warp(layers):
+    parts = []
+    for W, b in layers:
+        parts += [W.reshape(-1), b]
+    return torch.cat([p.detach().float() for p in parts])
+
+
+def unpack_warp(flat):
+    o, out = 0, []
+    for shp in ((128, 3), (128, 128), (128, 128), (128, 128), (4, 128)):
+        n = shp[0] * shp[1]
+        W = flat[o:o + n].reshape(shp); o += n
+        b = flat[o:o + shp[0]]; o += shp[0]
+        out.append((W, b))
+    return out
+
+
+class RenderCore:
+    """Forward and backward kernel chains over a Workspace.  Parameters are passed as raw device tensors:
+    k0_cl [X,Y,Z,C] (channels-last), sdf [X,Y,Z], flat (FlatParams-like with .view)."""
+
+    def __init__(self, cfg: SceneConfig):
+        self.cfg = cfg
+
+    # -- forward -------------------------------------------------------------------------------------------
+    def sample(self, ws, jitter):
+        ops.sample_dense(self.cfg.pp, ws.rays_o, ws.rays_d, jitter, ws.cap, ws.t_min, ws.t_max, ws.ray_start, ws.count,
+                         ws.pts, ws.ray_id, ws.step_k, ws.step)
+
+    def forward(self, ws, k0_cl, sdf, sdf_ab, rgbnet_p, warp_p, inv_s, pe_w, step_w=None):
+        cfg, sc = self.cfg, self.cfg.pp
+        ops.warp_fwd(warp_p, ws.pts, ws.count, ws.cap, cfg.out_range, ws.warp_acts, ws.warp_out)
+        ops.geometry_fwd(sc, sdf, sdf_ab, ws.pts, ws.warp_out, ws.viewdirs, ws.ray_id, ws.count, ws.cap, inv_s,
+                         ws.alpha, ws.gradient, ws.sdf_final, ws.sdf_deform, ws.grad_deform)
+        ops.color_feat_fwd(sc, k0_cl, ws.pts, ws.viewdirs, ws.ray_id, ws.gradient, pe_w, ws.count, ws.cap, ws.feat)
+        ops.rgbnet_fwd(rgbnet_p, ws.feat, ws.count, ws.cap, ws.rgb_acts, ws.rgb)
+        ops.march_fwd(ws.alpha, ws.rgb, ws.step if step_w is None else step_w, None, ws.ray_start, ws.N, cfg.bg,
+                      ws.weights, ws.T, ws.alphainv_last, ws.i_end, ws.rgb_marched, ws.rgb_pre, ws.cum_weights,
+                      ws.depth_acc, None)
+
+    # -- backward ------------------------------------------------------------------------------------------
+    def backward(self, ws, k0_cl, sdf, sdf_ab, rgbnet_p, warp_p, inv_s, pe_w, k0_grad_cl, sdf_ab_grad, rgbnet_grad,
+                 warp_grad, g_depth=None, g_weights=None, g_gradient_ext=None, g_sdf_deform=None, g_grad_deform=None,
+                 g_correction=None, g_alpha_ext=None, g_rgb_ext=None):
+        """Consumes ws.g_rgbm / ws.g_last / ws.g_cw (+ optional per-sample upstream grads), accumulates parameter
+        grads (atomic +=) and leaves d/d ray_pts in ws.g_pts and the per-sample viewdir grads in ws.g_view_s."""
+        cfg, sc = self.cfg, self.cfg.pp
+        ops.march_bwd(ws.alpha, ws.rgb, ws.step, ws.weights, ws.T, ws.alphainv_last, ws.ray_start, ws.i_end, ws.N, cfg.bg,
+                      ws.rgb_pre, ws.g_rgbm, ws.g_cw, ws.g_last, g_depth, g_weights, ws.g_alpha, ws.g_rgb)
+        if g_alpha_ext is not None:
+            ws.g_alpha.add_(g_alpha_ext)
+        if g_rgb_ext is not None:
+            ws.g_rgb.add_(g_rgb_ext)
+        ops.rgbnet_bwd(rgbnet_p, ws.feat, ws.rgb_acts, ws.rgb, ws.g_rgb, ws.count, ws.cap, ws.scratch.view(-1)[:2 * ws.cap * 128],
+                       rgbnet_grad, ws.g_feat)
+        ops.color_feat_bwd(sc, k0_cl, ws.pts, ws.viewdirs, ws.ray_id, ws.gradient, pe_w, ws.count, ws.cap, ws.g_feat,
+                           k0_grad_cl, ws.g_pts, ws.g_gradient, ws.g_view_s)
+        if g_gradient_ext is not None:
+            g_gradient_ext(ws)      # callable adding loss terms into ws.g_gradient etc. (fused step) ...
+        ops.geometry_bwd(sc, sdf, sdf_ab, ws.pts, ws.warp_out, ws.viewdirs, ws.ray_id, ws.count, ws.cap, inv_s,
+                         ws.g_alpha, ws.g_gradient, None, g_sdf_deform, g_grad_deform, g_correction, 1, ws.g_warp_out,
+                         ws.g_pts, ws.g_view_s, sdf_ab_grad)
+        ops.warp_bwd(warp_p, ws.pts, ws.warp_acts, ws.g_warp_out, ws.count, ws.cap, cfg.out_range, ws.scratch, warp_grad,
+                     ws.g_pts)
+
+
+class TrainEngine:
+    """Fused object-branch train step on one GPU (rank-local shard of the rays when world_size > 1)."""
+
+    LR = {'k0': 1e-1, 'rgbnet': 1e-3, 'warp': 1e-3, 'sdf_ab': 1e-2}     # configs/dtu_e2e/scan1.py:87-103
+
+    def __init__(self, cfg: SceneConfig, n_views, H, W, n_rand, device='cuda', lr_pose=1e-3, lr_pose_end=1e-4,
+                 pose_iters=1, lrate_decay=10, loss_scale=0.1, weight_main=1.0, weight_tv_k0=0.01, weight_mask=0.1,
+                 fix_first=True, capacity=None, x_slab=None, dist_ctx=None):
+        self.cfg, self.dev = cfg, torch.device(device)
+        self.V, self.H, self.W, self.N = n_views, H, W, n_rand
+        cap = capacity or n_rand * cfg.n_samples
+        self.ws = Workspace(n_rand, cap, self.dev)
+        self.core = RenderCore(cfg)
+        X, Y, Z = cfg.world_size
+        f = dict(dtype=torch.float32, device=self.dev)
+        self.k0 = [torch.zeros(X, Y, Z, cfg.k0_dim, **f), torch.zeros(X, Y, Z, cfg.k0_dim, **f)]   # ping-pong
+        self.k0_cur = 0
+        self.k0_grad, self.k0_m, self.k0_v = (torch.zeros(X, Y, Z, cfg.k0_dim, **f) for _ in range(3))
+        self.sdf = torch.zeros(X, Y, Z, **f)
+        self.flat = FlatParams(self.dev)
+        self.se3 = torch.zeros(n_views, 6, **f)
+        self.se3_grad, self.se3_m, self.se3_v = (torch.zeros(n_views, 6, **f) for _ in range(3))
+        self.w2c_init = torch.zeros(n_views, 3, 4, **f)
+        self.w2c, self.c2w = torch.zeros(n_views, 3, 4, **f), torch.zeros(n_views, 3, 4, **f)
+        self.jac = torch.zeros(n_views, 12, 6, **f)
+        self.c2w_grad = torch.zeros(n_views, 3, 4, **f)
+        mask = torch.ones(n_views, dtype=torch.int32)
+        if fix_first:
+            mask[0] = 0                     # get_current_pose_pnp never refines view 0 (recon_scene.py:68)
+        self.refine_mask = mask.to(self.dev)
+        self.intr = torch.zeros(n_views, 4, **f)
+        self.images = self.masks = None
+        self.lr = dict(self.LR)
+        self.lr_pose = lr_pose
+        self.pose_gamma = (lr_pose_end / (1e-10 + lr_pose)) ** (1. / pose_iters)
+        self.decay = 0.1 ** (1 / (lrate_decay * 1000))
+        self.loss_scale, self.w_main, self.w_tv, self.w_mask = loss_scale, weight_main, weight_tv_k0, weight_mask
+        self.n_step = 0
+        self.x_slab = x_slab or (0, X)
+        self.dist = dist_ctx
+        segs = [self.flat.off[n][0] + _pad(self.flat.off[n][1]) for n, _ in FlatParams.SEG]
+        self.seg_end = torch.tensor(segs, dtype=torch.int32, device=self.dev)
+        self.seg_lr = torch.zeros(len(segs), **f)
+        self.pose_seg_end = torch.tensor([n_views * 6], dtype=torch.int32, device=self.dev)
+        self.pose_seg_lr = torch.zeros(1, **f)
+        self.pe_w = torch.zeros(cfg.posbase_pe + cfg.viewbase_pe, **f)
+
+    # ---- data / parameter loading ---------------------------------------------------------------------------
+    def set_views(self, images, masks, Ks, w2c_init):
+        """images [V,H,W,3], masks [V,H,W,1|none], Ks [V,3,3], w2c_init [V,3,4] (numpy or torch)."""
+        t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32).to(self.dev).contiguous()
+        self.images, self.masks = t(images), t(masks).reshape(self.V, self.H, self.W).contiguous()
+        K = torch.as_tensor(np.asarray(Ks), dtype=torch.float32)
+        self.intr.copy_(torch.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], -1))
+        self.w2c_init.copy_(t(w2c_init))
+
+    @property
+    def k0_cl(self):
+        return self.k0[self.k0_cur]
+
+    def load_reference_params(self, k0, sdf, sdf_alpha, sdf_beta, rgbnet, warp, se3=None):
+        """k0 [1,C,X,Y,Z], sdf [1,1,X,Y,Z] in the reference layout (state_dict tensors)."""
+        with torch.no_grad():
+            self.k0_cl.copy_(k0[0].permute(1, 2, 3, 0).to(self.dev))
+            self.sdf.copy_(sdf[0, 0].to(self.dev))
+            d = lambda x: x.detach().to(self.dev)
+            self.flat.load_reference(d(sdf_alpha), d(sdf_beta), [(d(W), d(b)) for W, b in rgbnet],
+                                     [(d(W), d(b)) for W, b in warp])
+            if se3 is not None:
+                self.se3.copy_(se3.to(self.dev))
+
+    def k0_reference_layout(self, t=None):
+        t = self.k0_cl if t is None else t
+        return t.permute(3, 0, 1, 2)[None]
+
+    # ---- one step -------------------------------------------------------------------------------------------
+    def zero_grads(self):
+        self.k0_grad.zero_()
+        self.flat.grad.zero_()
+        self.se3_grad.zero_()
+
+    def render_and_grads(self, ray_idx, jitter, global_step):
+        """pose -> rays -> forward -> losses -> full backward.  Gradients are accumulated into k0_grad / flat.grad /
+        se3_grad (which must be zero on entry)."""
+        cfg, ws, sc = self.cfg, self.ws, self.cfg.pp
+        ops.pose_fwd(self.se3, self.w2c_init, self.refine_mask, self.w2c, self.c2w, self.jac)
+        ops.raygen_select_fwd(sc, ray_idx, self.c2w, self.intr, self.H, self.W, cfg.inverse_y, True, self.images, self.masks,
+                              ws.rays_o, ws.rays_d, ws.viewdirs, ws.target, ws.mask_px)
+        self.core.sample(ws, jitter)
+        progress = global_step / cfg.N_iters
+        self.pe_w.copy_(torch.from_numpy(cfg.pe_weights(progress)), non_blocking=True)
+        s_val = cfg.s_val(global_step)
+        inv_s = float(np.float32(1.0) / np.float32(s_val))
+        P = self.flat
+        self.core.forward(ws, self.k0_cl, self.sdf, P.view('sdf_ab'), P.view('rgbnet'), P.view('warp'), inv_s, self.pe_w)
+        ws.loss_out.zero_()
+        w_dyn = dynamic_weight(1e-1, 1e-3, global_step, cfg.N_iters)
+        ls = self.loss_scale
+        ops.loss_rays(ws.rgb_marched, ws.alphainv_last, ws.cum_weights, ws.target, ws.mask_px, ws.mask_sum, self.w_main,
+                      0.01, self.w_mask, ls, ws.g_rgbm, ws.g_last, ws.g_cw, ws.loss_out)
+
+        def add_sample_losses(w):
+            ops.loss_samples(w.gradient, w.grad_deform, w.warp_out, w.sdf_deform, w.count, w.cap, 1.0, w_dyn, ls,
+                             w.g_gradient, w.g_grad_deform, w.g_corr, w.g_sdf_deform, w.loss_out)
+
+        self.core.backward(ws, self.k0_cl, self.sdf, P.view('sdf_ab'), P.view('rgbnet'), P.view('warp'), inv_s, self.pe_w,
+                           self.k0_grad, P.view('sdf_ab', 'grad'), P.view('rgbnet', 'grad'), P.view('warp', 'grad'),
+                           g_gradient_ext=add_sample_losses, g_sdf_deform=ws.g_sdf_deform,
+                           g_grad_deform=ws.g_grad_deform, g_correction=ws.g_corr)
+        ops.raygen_select_bwd(sc, ray_idx, self.c2w, self.intr, self.H, self.W, cfg.inverse_y, ws.rays_o, ws.rays_d,
+                              ws.t_min, ws.ray_start, ws.g_pts, ws.step, ws.g_view_s, None, None, None, None, None, None,
+                              None, self.c2w_grad)
+        ops.pose_bwd(self.jac, self.c2w_grad, self.se3_grad)
+        return s_val, w_dyn
+
+    def optimizer_step(self, optimize_pose=True, grad_scale=1.0):
+        cfg = self.cfg
+        self.n_step += 1
+        for k in self.lr:                       # per-step exponential decay precedes the step (recon_scene.py:742-768)
+            self.lr[k] *= self.decay
+        X, Y, Z = cfg.world_size
+        tv_scale = self.loss_scale * self.w_tv / (3.0 * X * Y * Z * cfg.k0_dim)
+        src, dst = self.k0[self.k0_cur], self.k0[1 - self.k0_cur]
+        self.ws.tv_out.zero_()
+        xb, xe = self.x_slab
+        ops.grid_tv_adam_step(src, dst, self.k0_grad, self.k0_m, self.k0_v, cfg.world_size, cfg.k0_dim, xb, xe, tv_scale,
+                              grad_scale, self.lr['k0'], 0.9, 0.99, 1e-8, self.n_step, self.ws.tv_out)
+        self.k0_cur = 1 - self.k0_cur
+        self.seg_lr.copy_(torch.tensor([self.lr['sdf_ab'], self.lr['rgbnet'], self.lr['warp']]), non_blocking=True)
+        ops.adam_flat(self.flat.data, self.flat.grad, self.flat.m, self.flat.v, self.seg_end, self.seg_lr, grad_scale, 0.9,
+                      0.99, 1e-8, self.n_step, 1)
+        if optimize_pose:
+            self.pose_seg_lr.fill_(self.lr_pose)
+            ops.adam_flat(self.se3.view(-1), self.se3_grad.view(-1), self.se3_m.view(-1), self.se3_v.view(-1),
+                          self.pose_seg_end, self.pose_seg_lr, grad_scale, 0.9, 0.999, 1e-8, self.n_step, 1)
+            self.lr_pose *= self.pose_gamma
+
+    def train_step(self, ray_idx, jitter, global_step, optimize_pose=True):
+        """Gradients are zeroed by the optimiser kernels themselves after use; call zero_grads() once before the
+        first step."""
+        out = self.render_and_grads(ray_idx, jitter, global_step)
+        if self.dist is not None:
+            self.dist.reduce_gradients(self)
+        self.optimizer_step(optimize_pose, grad_scale=1.0)
+        if self.dist is not None:
+            self.dist.gather_parameters(self)
+        return out
+
+    def losses(self):
+        """dict of the unweighted loss scalars of the last step (one D2H copy)."""
+        v = self.ws.loss_out.cpu().numpy()
+        names = ['img_render', 'weight_entropy_last', 'grad_constraint', 'grad_deform_constraint',
+                 'sdf_correct_constraint', 'sdf_deform_constraint', 'mask_render']
+        return {n: float(v[i]) for i, n in enumerate(names)}

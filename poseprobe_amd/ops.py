@@ -1,0 +1,206 @@
+"""Thin, allocation-explicit Python wrappers over the C ABI (include/poseprobe_hip.h).
+
+One function per entry point; tensors are torch CUDA tensors used purely as device buffers (torch is
+plumbing: memory + streams).  Error behaviour mirrors the reference extension
+(lib/cuda/render_utils.cpp:46-48 CHECK_INPUT): non-CUDA or non-contiguous inputs raise RuntimeError.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import pp_scene
+
+
+def _ptr(t, dtype=None, name='tensor'):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name} must be a torch.Tensor')
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must be a CUDA tensor')
+    if not t.is_contiguous():
+        raise RuntimeError(f'{name} must be contiguous')
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f'{name} must be {dtype}, got {t.dtype}')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f(t, name='tensor'):
+    return _ptr(t, torch.float32, name)
+
+
+def _i(t, name='tensor'):
+    return _ptr(t, torch.int32, name)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_scene(xyz_min, xyz_max, world_size, voxel_size, stepsize, near, far, bg, out_range=1.0, k0_dim=12,
+               pos_pe=5, view_pe=1):
+    sc = pp_scene()
+    for i in range(3):
+        sc.xyz_min[i] = float(xyz_min[i])
+        sc.xyz_max[i] = float(xyz_max[i])
+        sc.size[i] = int(world_size[i])
+    sc.voxel_size = float(np.float32(voxel_size))
+    sc.stepsize = float(stepsize)
+    sc.near_clip = float(near)
+    sc.far_clip = float(far)
+    sc.bg = float(bg)
+    # voxurf_coarse.py:700
+    sc.n_samples = int(np.linalg.norm(np.array([int(w) for w in world_size]) + 1) / stepsize) + 1
+    sc.out_range = float(out_range)
+    sc.k0_dim, sc.pos_pe, sc.view_pe = int(k0_dim), int(pos_pe), int(view_pe)
+    return sc
+
+
+RGBNET_PARAMS = 128 * 64 + 128 + 2 * (128 * 128 + 128) + 3 * 128 + 3
+WARP_PARAMS = 128 * 3 + 128 + 3 * (128 * 128 + 128) + 4 * 128 + 4
+FEAT_LD = 64
+
+
+# ------------------------------------------------------------------------------------------- pose / rays
+def pose_fwd(se3, w2c_init, refine_mask, w2c, c2w, jac):
+    V = se3.shape[0]
+    _lib.call('pp_pose_fwd', _f(se3), _f(w2c_init), _i(refine_mask), V, _f(w2c), _f(c2w), _f(jac), _stream())
+
+
+def pose_bwd(jac, c2w_grad, se3_grad):
+    _lib.call('pp_pose_bwd', _f(jac), _f(c2w_grad), se3_grad.shape[0], _f(se3_grad), _stream())
+
+
+def raygen_select_fwd(sc, ray_idx, c2w, intr, H, W, inverse_y, normalize, images, masks, rays_o, rays_d, viewdirs,
+                      target, mask_px):
+    _lib.call('pp_raygen_select_fwd', ctypes.byref(sc), _i(ray_idx), ray_idx.shape[0], _f(c2w), _f(intr),
+              c2w.shape[0], H, W, int(inverse_y), int(normalize), _f(images), _f(masks), _f(rays_o), _f(rays_d),
+              _f(viewdirs), _f(target), _f(mask_px), _stream())
+
+
+def raygen_select_bwd(sc, ray_idx, c2w, intr, H, W, inverse_y, rays_o, rays_d, t_min, ray_start, pts_grad, step,
+                      vgrad_s, g_o, g_d, g_v, g_depth, g_o_out, g_d_out, g_v_out, c2w_grad):
+    n_views = c2w.shape[0] if c2w is not None else 0
+    _lib.call('pp_raygen_select_bwd', ctypes.byref(sc), _i(ray_idx), rays_o.shape[0], _f(c2w), _f(intr), n_views,
+              H, W, int(inverse_y), _f(rays_o), _f(rays_d), _f(t_min), _i(ray_start), _f(pts_grad), _f(step),
+              _f(vgrad_s), _f(g_o), _f(g_d), _f(g_v), _f(g_depth), _f(g_o_out), _f(g_d_out), _f(g_v_out),
+              _f(c2w_grad), _stream())
+
+
+def sample_dense(sc, rays_o, rays_d, jitter, capacity, t_min, t_max, ray_start, count, pts, ray_id, step_k, step,
+                 mask_keep=None):
+    _lib.call('pp_sample_dense', ctypes.byref(sc), _f(rays_o), _f(rays_d), _f(jitter), rays_o.shape[0], capacity,
+              _f(t_min), _f(t_max), _i(ray_start), _i(count), _f(pts), _i(ray_id), _i(step_k), _f(step),
+              _ptr(mask_keep, torch.uint8), _stream())
+
+
+def sample_var(sc, rays_o, rays_d, capacity, t_min, t_max, n_steps, ray_start, count, pts, ray_id, step_id):
+    _lib.call('pp_sample_var', ctypes.byref(sc), _f(rays_o), _f(rays_d), rays_o.shape[0], capacity, _f(t_min),
+              _f(t_max), _i(n_steps), _i(ray_start), _i(count), _f(pts), _i(ray_id), _i(step_id), _stream())
+
+
+# ------------------------------------------------------------------------------------------- scan / composite
+def alpha2weight_fwd(alpha, ray_start, n_rays, weights, T, alphainv_last, i_end):
+    _lib.call('pp_alpha2weight_fwd', _f(alpha), _i(ray_start), n_rays, _f(weights), _f(T), _f(alphainv_last),
+              _i(i_end), _stream())
+
+
+def alpha2weight_bwd(alpha, weights, T, alphainv_last, ray_start, i_end, n_rays, grad_weights, grad_last, grad_alpha):
+    _lib.call('pp_alpha2weight_bwd', _f(alpha), _f(weights), _f(T), _f(alphainv_last), _i(ray_start), _i(i_end),
+              n_rays, _f(grad_weights), _f(grad_last), _f(grad_alpha), _stream())
+
+
+def march_fwd(alpha, rgb, step_w, nrm_in, ray_start, n_rays, bg, weights, T, alphainv_last, i_end, rgb_marched,
+              rgb_pre, cum_weights, depth_acc, normal_marched):
+    _lib.call('pp_march_fwd', _f(alpha), _f(rgb), _f(step_w), _f(nrm_in), _i(ray_start), n_rays, float(bg),
+              _f(weights), _f(T), _f(alphainv_last), _i(i_end), _f(rgb_marched), _f(rgb_pre), _f(cum_weights),
+              _f(depth_acc), _f(normal_marched), _stream())
+
+
+def march_bwd(alpha, rgb, step_w, weights, T, alphainv_last, ray_start, i_end, n_rays, bg, rgb_pre, g_rgbm, g_cw,
+              g_last, g_depth, g_weights, grad_alpha, grad_rgb):
+    _lib.call('pp_march_bwd', _f(alpha), _f(rgb), _f(step_w), _f(weights), _f(T), _f(alphainv_last), _i(ray_start),
+              _i(i_end), n_rays, float(bg), _f(rgb_pre), _f(g_rgbm), _f(g_cw), _f(g_last), _f(g_depth),
+              _f(g_weights), _f(grad_alpha), _f(grad_rgb), _stream())
+
+
+# ------------------------------------------------------------------------------------------- geometry / colour
+def geometry_fwd(sc, sdf_grid, sdf_ab, pts, warp_out, viewdirs, ray_id, count, capacity, inv_s, alpha, gradient,
+                 sdf_final, sdf_deform, grad_deform):
+    _lib.call('pp_geometry_fwd', ctypes.byref(sc), _f(sdf_grid), _f(sdf_ab), _f(pts), _f(warp_out), _f(viewdirs),
+              _i(ray_id), _i(count), capacity, float(inv_s), _f(alpha), _f(gradient), _f(sdf_final), _f(sdf_deform),
+              _f(grad_deform), _stream())
+
+
+def geometry_bwd(sc, sdf_grid, sdf_ab, pts, warp_out, viewdirs, ray_id, count, capacity, inv_s, g_alpha, g_gradient,
+                 g_sdf_final, g_sdf_deform, g_grad_deform, g_correction, accumulate, warp_out_grad, pts_grad, vgrad_s,
+                 sdf_ab_grad):
+    _lib.call('pp_geometry_bwd', ctypes.byref(sc), _f(sdf_grid), _f(sdf_ab), _f(pts), _f(warp_out), _f(viewdirs),
+              _i(ray_id), _i(count), capacity, float(inv_s), _f(g_alpha), _f(g_gradient), _f(g_sdf_final),
+              _f(g_sdf_deform), _f(g_grad_deform), _f(g_correction), int(accumulate), _f(warp_out_grad),
+              _f(pts_grad), _f(vgrad_s), _f(sdf_ab_grad), _stream())
+
+
+def color_feat_fwd(sc, k0_cl, pts, viewdirs, ray_id, gradient, pe_w, count, capacity, feat):
+    _lib.call('pp_color_feat_fwd', ctypes.byref(sc), _f(k0_cl), _f(pts), _f(viewdirs), _i(ray_id), _f(gradient),
+              _f(pe_w), _i(count), capacity, _f(feat), _stream())
+
+
+def color_feat_bwd(sc, k0_cl, pts, viewdirs, ray_id, gradient, pe_w, count, capacity, feat_grad, k0_grad_cl, pts_grad,
+                   gradient_grad, vgrad_s):
+    _lib.call('pp_color_feat_bwd', ctypes.byref(sc), _f(k0_cl), _f(pts), _f(viewdirs), _i(ray_id), _f(gradient),
+              _f(pe_w), _i(count), capacity, _f(feat_grad), _f(k0_grad_cl), _f(pts_grad), _f(gradient_grad),
+              _f(vgrad_s), _stream())
+
+
+# ------------------------------------------------------------------------------------------- MLPs
+def rgbnet_fwd(params, feat, count, capacity, acts, rgb):
+    _lib.call('pp_rgbnet_fwd', _f(params), _f(feat), _i(count), capacity, _f(acts), _f(rgb), _stream())
+
+
+def rgbnet_bwd(params, feat, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad):
+    _lib.call('pp_rgbnet_bwd', _f(params), _f(feat), _f(acts), _f(rgb), _f(rgb_grad), _i(count), capacity,
+              _f(scratch), _f(params_grad), _f(feat_grad), _stream())
+
+
+def warp_fwd(params, pts, count, capacity, out_range, acts, out):
+    _lib.call('pp_warp_fwd', _f(params), _f(pts), _i(count), capacity, float(out_range), _f(acts), _f(out), _stream())
+
+
+def warp_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad):
+    _lib.call('pp_warp_bwd', _f(params), _f(pts), _f(acts), _f(out_grad), _i(count), capacity, float(out_range),
+              _f(scratch), _f(params_grad), _f(pts_grad), _stream())
+
+
+# ------------------------------------------------------------------------------------------- losses / optimiser
+def loss_rays(rgb_marched, alphainv_last, cum_weights, target, mask_px, mask_sum, w_main, w_entropy, w_mask,
+              loss_scale, g_rgbm, g_last, g_cw, loss_out):
+    _lib.call('pp_loss_rays', _f(rgb_marched), _f(alphainv_last), _f(cum_weights), _f(target), _f(mask_px),
+              _f(mask_sum), rgb_marched.shape[0], float(w_main), float(w_entropy), float(w_mask), float(loss_scale),
+              _f(g_rgbm), _f(g_last), _f(g_cw), _f(loss_out), _stream())
+
+
+def loss_samples(gradient, grad_deform, warp_out, sdf_deform, count, capacity, w_eik, w_deform, loss_scale, g_gradient,
+                 g_grad_deform, g_correction, g_sdf_deform, loss_out):
+    _lib.call('pp_loss_samples', _f(gradient), _f(grad_deform), _f(warp_out), _f(sdf_deform), _i(count), capacity,
+              float(w_eik), float(w_deform), float(loss_scale), _f(g_gradient), _f(g_grad_deform), _f(g_correction),
+              _f(g_sdf_deform), _f(loss_out), _stream())
+
+
+def grid_tv_adam_step(p_in, p_out, grad, exp_avg, exp_avg_sq, size, channels, x_begin, x_end, tv_scale, grad_scale, lr,
+                      beta1, beta2, eps, step, tv_out):
+    _lib.call('pp_grid_tv_adam_step', _f(p_in), _f(p_out), _f(grad), _f(exp_avg), _f(exp_avg_sq),
+              int(size[0]), int(size[1]), int(size[2]), channels, x_begin, x_end, float(tv_scale), float(grad_scale),
+              float(lr), float(beta1), float(beta2), float(eps), int(step), _f(tv_out), _stream())
+
+
+def grid_tv_value(p, size, channels, out):
+    _lib.call('pp_grid_tv_value', _f(p), int(size[0]), int(size[1]), int(size[2]), channels, _f(out), _stream())
+
+
+def adam_flat(p, grad, exp_avg, exp_avg_sq, seg_end, seg_lr, grad_scale, beta1, beta2, eps, step, zero_grad):
+    _lib.call('pp_adam_flat', _f(p), _f(grad), _f(exp_avg), _f(exp_avg_sq), p.numel(), _i(seg_end), _f(seg_lr),
+              seg_end.numel(), float(grad_scale), float(beta1), float(beta2), float(eps), int(step), int(zero_grad),
+              _stream())

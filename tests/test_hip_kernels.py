@@ -1,0 +1,195 @@
+"""GPU parity tests, kernel level: every test calls the HIP path through the C ABI (poseprobe_amd.ops) and checks
+it against the oracle (CPU restatement) or the golden vectors produced by the reference."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close, load, scene_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(G, **kw):
+    from poseprobe_amd import synthetic as syn
+    from poseprobe_amd.engine import SceneConfig
+    rs = syn.range_shape()
+    return SceneConfig(syn.XYZ_MIN, syn.XYZ_MAX, int(G) ** 3, out_range=float(rs.max()), **kw)
+
+
+def cu(x, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x)).to('cuda', dtype).contiguous()
+
+
+def test_library_loaded_and_fails_loudly_without_gpu_tensors():
+    from poseprobe_amd import _lib, ops
+    assert _lib.lib().pp_abi_version() == 1
+    a = torch.zeros(4)
+    with pytest.raises(RuntimeError):
+        ops.alpha2weight_fwd(a, a, 1, a, a, a, a)
+
+
+def test_pose_fwd_bwd_matches_reference_golden():
+    from poseprobe_amd import ops
+    d = load('pose.npz')
+    V = d['wu'].shape[0]
+    se3, init = cu(d['wu']), cu(d['init'])
+    w2c, c2w = torch.empty(V, 3, 4, device='cuda'), torch.empty(V, 3, 4, device='cuda')
+    jac = torch.empty(V, 12, 6, device='cuda')
+    ops.pose_fwd(se3, init, None, w2c, c2w, jac)
+    assert_close(w2c.cpu(), d['composed'], rtol=1e-6, atol=1e-6, name='w2c')
+    assert_close(c2w.cpu(), d['inverted'], rtol=1e-6, atol=1e-6, name='c2w')
+    g = torch.empty(V, 6, device='cuda')
+    ops.pose_bwd(jac, cu(d['wsum']), g)
+    assert_close(g.cpu(), d['grad_wu'], rtol=1e-4, atol=1e-6, name='grad_se3')
+
+
+def test_raygen_selected_pixels_bit_exact():
+    from poseprobe_amd import ops
+    d = load('rays.npz')
+    H, W, V = 8, 12, 3
+    cfg = _cfg(8)
+    Ks = d['Ks']
+    intr = cu(np.stack([Ks[:, 0, 0], Ks[:, 1, 1], Ks[:, 0, 2], Ks[:, 1, 2]], -1))
+    c2w = cu(d['c2w'][:, :3, :4])
+    idx = torch.arange(V * H * W, dtype=torch.int32, device='cuda')
+    N = idx.numel()
+    for inv_y in (True, False):
+        for normalize, pre in ((True, 'vox'), (False, 'dvgo')):
+            o, dd, vd = (torch.empty(N, 3, device='cuda') for _ in range(3))
+            ops.raygen_select_fwd(cfg.pp, idx, c2w, intr, H, W, inv_y, normalize, None, None, o, dd, vd, None, None)
+            for v in range(V):
+                tag = f'v{v}_invy{int(inv_y)}'
+                sl = slice(v * H * W, (v + 1) * H * W)
+                assert np.array_equal(dd[sl].cpu().numpy().reshape(H, W, 3), d[f'{pre}_d_{tag}']), (pre, tag, 'd')
+                assert np.array_equal(vd[sl].cpu().numpy().reshape(H, W, 3), d[f'{pre}_v_{tag}']), (pre, tag, 'v')
+                assert np.array_equal(o[sl].cpu().numpy().reshape(H, W, 3), d[f'{pre}_o_{tag}']), (pre, tag, 'o')
+
+
+@pytest.mark.parametrize('tag', ['g8', 'g24'])
+def test_dense_sampler_indices_bit_exact(tag):
+    """ray/sample indices, steps, t_min/t_max AND sample positions bit-exact against the reference's sample_ray_ori."""
+    from poseprobe_amd import ops
+    d = load(f'sampler_{tag}.npz')
+    cfg = _cfg(d['G'])
+    ro, rd = cu(d['rays_o']), cu(d['rays_d'])
+    N, S = ro.shape[0], cfg.n_samples
+    assert S == d['mask_out_train'].shape[1]
+    for sfx, jit in (('train', cu(d['jitter'])), ('eval', None)):
+        cap = N * S
+        f, i = dict(device='cuda'), dict(device='cuda', dtype=torch.int32)
+        t_min, t_max = torch.empty(N, **f), torch.empty(N, **f)
+        ray_start, count = torch.empty(N + 1, **i), torch.empty(1, **i)
+        pts, ray_id, step_k, step = torch.empty(cap, 3, **f), torch.empty(cap, **i), torch.empty(cap, **i), torch.empty(cap, **f)
+        keep = torch.empty(N * S, device='cuda', dtype=torch.uint8)
+        ops.sample_dense(cfg.pp, ro, rd, jit, cap, t_min, t_max, ray_start, count, pts, ray_id, step_k, step, keep)
+        M = int(count.item())
+        ref_keep = ~d[f'mask_out_{sfx}']
+        assert np.array_equal(keep.cpu().numpy().reshape(N, S).astype(bool), ref_keep)
+        rid, sk = np.nonzero(ref_keep)
+        assert M == len(rid)
+        assert np.array_equal(ray_id[:M].cpu().numpy(), rid)
+        assert np.array_equal(step_k[:M].cpu().numpy(), sk)
+        assert np.array_equal(step[:M].cpu().numpy(), d[f'step_{sfx}'][ref_keep])
+        assert np.array_equal(pts[:M].cpu().numpy(), d[f'pts_{sfx}'][ref_keep])
+        assert np.array_equal(t_min.cpu().numpy(), d[f't_min_{sfx}'])
+        assert np.array_equal(t_max.cpu().numpy(), d[f't_max_{sfx}'])
+        assert int(ray_start[-1].item()) == M
+
+
+def _random_segments(n_rays, max_len, seed, hot=False):
+    rng = np.random.RandomState(seed)
+    lens = rng.randint(0, max_len, size=n_rays)
+    lens[rng.rand(n_rays) < 0.1] = 0            # empty rays
+    lens[:3] = [1, 64, 65]                      # single sample, exact wave, wave+1
+    ray_id = np.repeat(np.arange(n_rays), lens)
+    M = int(lens.sum())
+    alpha = rng.rand(M).astype(np.float32) * (0.6 if hot else 0.05)
+    alpha[rng.rand(M) < 0.02] = 0.0
+    if hot:
+        alpha[rng.rand(M) < 0.01] = 1.0
+    start = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    return alpha, ray_id.astype(np.int64), start, M
+
+
+@pytest.mark.parametrize('hot', [False, True])
+def test_alpha2weight_fwd_bwd_exact(hot):
+    """Sequential-order wave scan reproduces the oracle's (and the .cu's) arithmetic exactly, incl. the 1e-3 early stop."""
+    from oracle import native_ops
+    from poseprobe_amd import ops
+    N = 300
+    alpha, ray_id, start, M = _random_segments(N, 200, 5, hot)
+    w0, T0, last0, is0, ie0 = native_ops.alpha2weight(torch.tensor(alpha), torch.tensor(ray_id), N)
+    a, rs = cu(alpha), cu(start, torch.int32)
+    w, T, last = torch.empty(M, device='cuda'), torch.empty(M, device='cuda'), torch.empty(N, device='cuda')
+    i_end = torch.empty(N, device='cuda', dtype=torch.int32)
+    ops.alpha2weight_fwd(a, rs, N, w, T, last, i_end)
+    assert np.array_equal(w.cpu().numpy(), w0.numpy())
+    assert np.array_equal(T.cpu().numpy(), T0.numpy())
+    assert np.array_equal(last.cpu().numpy(), last0.numpy())
+    nonempty = start[1:] > start[:-1]
+    assert np.array_equal(i_end.cpu().numpy()[nonempty], ie0.numpy()[nonempty])
+    if hot:
+        assert (ie0.numpy()[nonempty] < start[1:][nonempty]).any(), 'test must exercise the early stop'
+    rng = np.random.RandomState(1)
+    gw, gl = rng.randn(M).astype(np.float32), rng.randn(N).astype(np.float32)
+    g0 = native_ops.alpha2weight_backward(torch.tensor(alpha), w0, T0, last0, is0, ie0, N, torch.tensor(gw), torch.tensor(gl))
+    g = torch.empty(M, device='cuda')
+    ops.alpha2weight_bwd(a, w, T, last, rs, i_end, N, cu(gw), cu(gl), g)
+    assert np.array_equal(g.cpu().numpy(), g0.numpy())
+
+
+def test_flat_adam_matches_reference_trajectory():
+    from poseprobe_amd import ops
+    d = load('adam.npz')
+    p = cu(d['p0'].reshape(-1))
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    seg_end = torch.tensor([p.numel()], dtype=torch.int32, device='cuda')
+    lr = 0.1
+    for s in range(3):
+        lr *= 0.1 ** (1 / 10000)
+        g = cu(d['grads'][s].reshape(-1))
+        ops.adam_flat(p, g, m, v, seg_end, torch.tensor([lr], device='cuda'), 1.0, 0.9, 0.99, 1e-8, s + 1, 1)
+        assert_close(p.cpu().numpy().reshape(4, 5), d['traj'][s], rtol=2e-6, atol=1e-7, name=f'adam step {s}')
+        assert float(g.abs().max()) == 0.0
+    assert_close(m.cpu().numpy().reshape(4, 5), d['exp_avg'], rtol=2e-6, atol=1e-8)
+    assert_close(v.cpu().numpy().reshape(4, 5), d['exp_avg_sq'], rtol=2e-6, atol=1e-10)
+
+
+@pytest.mark.parametrize('shape', [(5, 6, 7), (16, 12, 9)])
+def test_grid_tv_adam_step_matches_oracle(shape):
+    """Fused TV-gradient + Adam + zero-fill on the channels-last grid == oracle total_variation autograd + adam_update."""
+    from oracle import voxurf_oracle as O
+    from poseprobe_amd import ops
+    X, Y, Z = shape
+    C = 12
+    g = torch.Generator().manual_seed(3)
+    k0 = (torch.randn(1, C, X, Y, Z, generator=g) * 0.1)
+    k0[0, :, 1, 1, 1] = k0[0, :, 1, 1, 2]             # exact ties -> sign(0) = 0
+    grad_render = torch.randn(1, C, X, Y, Z, generator=g) * 1e-3
+    m0 = torch.randn(1, C, X, Y, Z, generator=g) * 1e-3
+    v0 = torch.rand(1, C, X, Y, Z, generator=g) * 1e-6
+    ls, w_tv, lr, step = 0.1, 0.01, 0.0977, 7
+    # oracle
+    p = k0.clone().requires_grad_(True)
+    tv = O.total_variation(p)
+    (tv * w_tv * ls).backward()
+    gtot = p.grad + grad_render
+    p_ref, m_ref, v_ref = k0.clone(), m0.clone(), v0.clone()
+    O.adam_update(p_ref, gtot, m_ref, v_ref, step, lr)
+    # HIP
+    cl = lambda t: t[0].permute(1, 2, 3, 0).contiguous().cuda()
+    p_in, p_out = cl(k0), torch.empty(X, Y, Z, C, device='cuda')
+    gr, m, v = cl(grad_render), cl(m0), cl(v0)
+    tv_out = torch.zeros(1, device='cuda')
+    for xb, xe in ((0, X // 2), (X // 2, X)):      # two x-slabs, as two ranks would do
+        ops.grid_tv_adam_step(p_in, p_out, gr, m, v, (X, Y, Z), C, xb, xe, ls * w_tv / (3 * k0.numel()), 1.0, lr, 0.9,
+                              0.99, 1e-8, step, tv_out)
+    back = lambda t: t.permute(3, 0, 1, 2)[None].cpu()
+    assert_close(back(p_out), p_ref, rtol=1e-5, atol=1e-7, name='p')
+    assert_close(back(m), m_ref, rtol=1e-5, atol=1e-9, name='m')
+    assert_close(back(v), v_ref, rtol=1e-5, atol=1e-12, name='v')
+    assert float(gr.abs().max()) == 0.0
+    assert_close(tv_out.cpu() / (3 * k0.numel()), tv.detach(), rtol=1e-5, name='tv value')
+    tv2 = torch.zeros(1, device='cuda')
+    ops.grid_tv_value(p_in, (X, Y, Z), C, tv2)
+    assert_close(tv2.cpu() / (3 * k0.numel()), tv.detach(), rtol=1e-5, name='tv value (standalone)')
