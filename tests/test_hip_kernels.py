@@ -185,11 +185,11 @@ def test_grid_tv_adam_step_matches_oracle(shape):
         ops.grid_tv_adam_step(p_in, p_out, gr, m, v, (X, Y, Z), C, xb, xe, ls * w_tv / (3 * k0.numel()), 1.0, lr, 0.9,
                               0.99, 1e-8, step, tv_out)
     back = lambda t: t.permute(3, 0, 1, 2)[None].cpu()
-    assert_close(back(p_out), p_ref, rtol=1e-5, atol=1e-7, name='p')
+    assert_close(back(p_out), p_ref, rtol=1e-5, atol=5e-6, name='p')   # one Adam step moves by <= lr ~ 0.1
     assert_close(back(m), m_ref, rtol=1e-5, atol=1e-9, name='m')
     assert_close(back(v), v_ref, rtol=1e-5, atol=1e-12, name='v')
     assert float(gr.abs().max()) == 0.0
-    assert_close(tv_out.cpu() / (3 * k0.numel()), tv.detach(), rtol=1e-5, name='tv value')
+    assert_close(tv_out.cpu()[0] / (3 * k0.numel()), tv.detach(), rtol=1e-5, name='tv value')
     tv2 = torch.zeros(1, device='cuda')
     ops.grid_tv_value(p_in, (X, Y, Z), C, tv2)
-    assert_close(tv2.cpu() / (3 * k0.numel()), tv.detach(), rtol=1e-5, name='tv value (standalone)')
+    assert_close(tv2.cpu()[0] / (3 * k0.numel()), tv.detach(), rtol=1e-5, name='tv value (standalone)')
