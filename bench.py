@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py - rays/s of one object-branch TRAIN STEP (ray select -> render -> loss -> backward -> optimiser step) on
+the BASELINE.json workload: DTU-scan1-like 3 views of 400x400, 160^3 grid, 186 samples/ray, N_rand = 1024 rays per
+GPU (weak scaling: global batch = 1024 * n_gpus), fp32, synthetic inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
+  roofline     - the dominant kernel (fused TV+Adam pass over the dense k0 grid, HBM bound): algorithmic bytes per
+                 launch (384 B/voxel) / mean launch duration measured with HIP events on the launch stream
+  cpu_baseline - the oracle (CPU restatement, "port") timed on this host's cores for a bounded sample (N=1, rank 0)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from poseprobe_amd import synthetic as syn            # noqa: E402
+from poseprobe_amd.engine import SceneConfig, TrainEngine   # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X spec (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+GRID_BYTES_PER_VOXEL = 384  # fused pass, C=12 fp32: read p,g,m,v (192) + write p',m,v,g=0 (192)
+
+
+def init_engine_params(eng, cfg, seed):
+    """Random-init parameters of the reference's architecture (cube-init SDF, k0~N(0,.1), warp last layer N(0,1e-2))."""
+    from poseprobe_amd.params_init import reference_like_params
+    P = reference_like_params(cfg, seed)
+    eng.load_reference_params(P['k0'], P['sdf'], P['sdf_alpha'], P['sdf_beta'], P['rgbnet'], P['warp'],
+                              se3=torch.tensor(syn.se3_perturbation(eng.V)))
+    return P
+
+
+def cpu_baseline(G, H, W, V, n_rand, views, budget_s=20.0):
+    """Oracle train step on the host cores: bounded sample of the SAME workload."""
+    from oracle import voxurf_oracle as O
+    rs = syn.range_shape()
+    scene = O.Scene(syn.XYZ_MIN, syn.XYZ_MAX, G ** 3, output_range=float(rs.max()), rect_size=rs.tolist())
+    P = O.init_params(scene, seed=3)
+    st = O.TrainState(P, scene, torch.tensor(views['w2c']), torch.tensor(views['Ks']), torch.tensor(views['images']),
+                      torch.tensor(views['masks']), se3_refine=torch.tensor(syn.se3_perturbation(V)), pose_iters=1000)
+    times = []
+    t_start = time.time()
+    s = 0
+    while True:
+        idx, jit = syn.step_randomness(V * H * W, n_rand, seed=1000 + s)
+        t0 = time.time()
+        st.step(torch.tensor(idx), torch.tensor(jit), 10 + s)
+        times.append(time.time() - t0)
+        s += 1
+        if s >= 2 and (time.time() - t_start > budget_s or s >= 12):
+            break
+    t = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    return {'value': n_rand / t, 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{len(times)} oracle train steps (torch-CPU fp32, {n_rand} rays, {G}^3 grid, first step dropped), '
+                      f'median {t:.3f} s/step'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--grid', type=int, default=160)
+    ap.add_argument('--n-rand', type=int, default=1024)
+    ap.add_argument('--hw', type=int, default=400)
+    ap.add_argument('--views', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dctx = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+        from poseprobe_amd.dist import DistContext
+        dctx = DistContext()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    G, H, W, V, N = args.grid, args.hw, args.hw, args.views, args.n_rand
+    rs = syn.range_shape()
+    cfg = SceneConfig(syn.XYZ_MIN, syn.XYZ_MAX, G ** 3, out_range=float(rs.max()))
+    views = syn.make_views(V, H, W)
+    eng = TrainEngine(cfg, V, H, W, N, device=dev, pose_iters=3000, dist_ctx=dctx)
+    eng.set_views(views['images'], views['masks'], views['Ks'], views['w2c'])
+    init_engine_params(eng, cfg, seed=3)
+    eng.zero_grads()
+
+    # every step's randomness is generated up front and is resident on the device: rank r takes its own ray shard
+    total = args.steps + args.warmup
+    idx_all, jit_all = [], []
+    for s in range(total):
+        idx, jit = syn.step_randomness(V * H * W, N * world, seed=2000 + s)
+        idx_all.append(idx[rank::world])
+        jit_all.append(jit[rank::world])
+    idx_all = torch.tensor(np.stack(idx_all), dtype=torch.int32, device=dev)
+    jit_all = torch.tensor(np.stack(jit_all), dtype=torch.float32, device=dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # time the dominant kernel with HIP events on the launch stream (torch's current stream == our launch stream)
+    from poseprobe_amd import ops
+    ev = []
+    orig = ops.grid_tv_adam_step
+
+    def timed_grid_step(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(*a, **k)
+        e1.record()
+        ev.append((e0, e1))
+
+    ops.grid_tv_adam_step = timed_grid_step
+
+    gs = 10
+    for s in range(args.warmup):
+        eng.train_step(idx_all[s], jit_all[s], gs + s)
+    barrier()
+    ev.clear()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total):
+        eng.train_step(idx_all[s], jit_all[s], gs + s)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    M = int(eng.ws.count.item())
+    grid_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float('nan')
+    xb, xe = eng.x_slab
+    X, Y, Z = cfg.world_size
+    grid_bytes = GRID_BYTES_PER_VOXEL * (xe - xb) * Y * Z
+    achieved = grid_bytes / (grid_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            'metric': 'rays_per_sec_train_step', 'value': N * world * args.steps / dt, 'unit': 'rays/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'DTU-scan1-like {V}-view {H}x{W}, object-branch train step (ray select, render, '
+                                   f'losses, backward, TV+Adam), {G}^3 grid, {cfg.n_samples} samples/ray, '
+                                   f'N_rand={N}/GPU', 'grid': G, 'n_rand_per_gpu': N, 'samples_in_bbox_last_step': M,
+                       'parallelism': f'ray-sharded dp{world}, ZeRO-1 grid optimiser' if world > 1 else 'single GPU'},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_grid_tv_adam (fused TV-grad + Adam + zero-grad over k0)',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'ms_per_launch': grid_ms, 'algorithmic_bytes_per_launch': grid_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(G, H, W, V, N, views, args.cpu_budget)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

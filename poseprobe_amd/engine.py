@@ -378,9 +378,10 @@ class TrainEngine:
         """Gradients are zeroed by the optimiser kernels themselves after use; call zero_grads() once before the
         first step."""
         out = self.render_and_grads(ray_idx, jitter, global_step)
+        self.grad_scale = 1.0
         if self.dist is not None:
-            self.dist.reduce_gradients(self)
-        self.optimizer_step(optimize_pose, grad_scale=1.0)
+            self.dist.reduce_gradients(self)          # sets x_slab and grad_scale = 1/world
+        self.optimizer_step(optimize_pose, grad_scale=self.grad_scale)
         if self.dist is not None:
             self.dist.gather_parameters(self)
         return out
