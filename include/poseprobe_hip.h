@@ -220,6 +220,17 @@ int pp_adam_flat(float* p, float* grad, float* exp_avg, float* exp_avg_sq, int32
 int pp_grid_tv_value(const float* p, int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, float* out,
                      void* stream);
 
+/* Generic trilinear lookup on a channels-last grid [X,Y,Z,C] (C<=16): DenseGrid.forward (lib/grid.py:47-58; border=0
+ * zeros padding) and grid_sampler's F.grid_sample path (lib/voxurf_coarse.py:540, lib/dvgo_ori.py:249-261; border=1).
+ * pts[n,3] world coords -> out[n,C].  Backward: grid_grad_cl (atomic +=, may be NULL), pts_grad[n,3] (=, may be NULL). */
+int pp_grid_sample_fwd(const pp_scene* sc, const float* grid_cl, int32_t channels, const float* pts, int32_t n_pts,
+                       int32_t border, float* out, void* stream);
+int pp_grid_sample_bwd(const pp_scene* sc, const float* grid_cl, int32_t channels, const float* pts, int32_t n_pts,
+                       int32_t border, const float* out_grad, float* grid_grad_cl, float* pts_grad, void* stream);
+/* total_variation backward (voxurf_coarse.py:1298-1313): grad += scale * g_scalar[0] * d(sum|diff|)/dp. */
+int pp_grid_tv_grad(const float* p, int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, float scale,
+                    const float* g_scalar, float* grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

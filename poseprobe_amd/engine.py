@@ -77,10 +77,11 @@ def dynamic_weight(w0, w1, it, total):
 class Workspace:
     """All per-ray / per-sample device buffers for N rays and `capacity` samples (default N*S)."""
 
-    def __init__(self, N, capacity, device):
+    def __init__(self, N, capacity, device, sample_capacity=None, backward=True):
         f = dict(dtype=torch.float32, device=device)
         i = dict(dtype=torch.int32, device=device)
         self.N, self.cap = N, capacity
+        self.sample_cap = sc_ = sample_capacity or capacity
         e = torch.empty
         # rays
         self.rays_o, self.rays_d, self.viewdirs = e(N, 3, **f), e(N, 3, **f), e(N, 3, **f)
@@ -89,7 +90,7 @@ class Workspace:
         self.ray_start = torch.zeros(N + 1, **i)
         self.count = torch.zeros(1, **i)
         # samples
-        self.pts, self.ray_id, self.step_k, self.step = e(capacity, 3, **f), e(capacity, **i), e(capacity, **i), e(capacity, **f)
+        self.pts, self.ray_id, self.step_k, self.step = e(sc_, 3, **f), e(sc_, **i), e(sc_, **i), e(sc_, **f)
         self.warp_acts = e(4, capacity * 4, 128, **f)
         self.warp_out = e(capacity, 16, **f)
         self.alpha, self.gradient = e(capacity, **f), e(capacity, 3, **f)
@@ -102,6 +103,11 @@ class Workspace:
         self.alphainv_last, self.i_end = e(N, **f), e(N, **i)
         self.rgb_marched, self.rgb_pre = e(N, 3, **f), e(N, 3, **f)
         self.cum_weights, self.depth_acc = e(N, **f), e(N, **f)
+        self.mask_sum = torch.zeros(1, **f)
+        self.loss_out = torch.zeros(8, **f)
+        self.tv_out = torch.zeros(1, **f)
+        if not backward:
+            return
         # backward buffers
         self.g_rgbm, self.g_last, self.g_cw = e(N, 3, **f), e(N, **f), e(N, **f)
         self.g_alpha, self.g_rgb = e(capacity, **f), e(capacity, 3, **f)
@@ -110,9 +116,6 @@ class Workspace:
         self.g_grad_deform, self.g_corr, self.g_sdf_deform = e(capacity, 9, **f), e(capacity, **f), e(capacity, **f)
         self.g_warp_out = e(capacity, 16, **f)
         self.scratch = e(2, capacity * 4, 128, **f)     # shared by both MLP backward chains
-        self.mask_sum = torch.zeros(1, **f)
-        self.loss_out = torch.zeros(8, **f)
-        self.tv_out = torch.zeros(1, **f)
         self.g_rays_o, self.g_rays_d, self.g_viewdirs = e(N, 3, **f), e(N, 3, **f), e(N, 3, **f)
 
 
@@ -197,7 +200,7 @@ class RenderCore:
 
     # -- forward -------------------------------------------------------------------------------------------
     def sample(self, ws, jitter):
-        ops.sample_dense(self.cfg.pp, ws.rays_o, ws.rays_d, jitter, ws.cap, ws.t_min, ws.t_max, ws.ray_start, ws.count,
+        ops.sample_dense(self.cfg.pp, ws.rays_o, ws.rays_d, jitter, ws.sample_cap, ws.t_min, ws.t_max, ws.ray_start, ws.count,
                          ws.pts, ws.ray_id, ws.step_k, ws.step)
 
     def forward(self, ws, k0_cl, sdf, sdf_ab, rgbnet_p, warp_p, inv_s, pe_w, step_w=None):

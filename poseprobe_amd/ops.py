@@ -204,3 +204,18 @@ def adam_flat(p, grad, exp_avg, exp_avg_sq, seg_end, seg_lr, grad_scale, beta1, 
     _lib.call('pp_adam_flat', _f(p), _f(grad), _f(exp_avg), _f(exp_avg_sq), p.numel(), _i(seg_end), _f(seg_lr),
               seg_end.numel(), float(grad_scale), float(beta1), float(beta2), float(eps), int(step), int(zero_grad),
               _stream())
+
+
+def grid_sample_fwd(sc, grid_cl, channels, pts, border, out):
+    _lib.call('pp_grid_sample_fwd', ctypes.byref(sc), _f(grid_cl), channels, _f(pts), pts.shape[0], int(border), _f(out),
+              _stream())
+
+
+def grid_sample_bwd(sc, grid_cl, channels, pts, border, out_grad, grid_grad_cl, pts_grad):
+    _lib.call('pp_grid_sample_bwd', ctypes.byref(sc), _f(grid_cl), channels, _f(pts), pts.shape[0], int(border),
+              _f(out_grad), _f(grid_grad_cl), _f(pts_grad), _stream())
+
+
+def grid_tv_grad(p, size, channels, scale, g_scalar, grad):
+    _lib.call('pp_grid_tv_grad', _f(p), int(size[0]), int(size[1]), int(size[2]), channels, float(scale), _f(g_scalar),
+              _f(grad), _stream())

@@ -1,0 +1,623 @@
+"""Drop-in for the reference's `lib/voxurf_coarse.py` module surface (imported there as `Model`):
+`Voxurf`, `pose_model`, `Alphas2Weights`, `total_variation`, `get_rays*`, `get_training_rays*`.
+
+Same constructor kwargs, forward/inference signatures, return-dict keys, `get_kwargs()` and `state_dict` names
+(SURVEY.md 8b); everything per ray / per sample runs in libposeprobe_hip.so through ONE autograd node whose backward
+is the hand-derived kernel chain (engine.RenderCore.backward).  There is no eager / CPU fallback: the module refuses
+to run on non-CUDA tensors.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import camera, grid, ops
+from .engine import (FlatParams, RenderCore, SceneConfig, Workspace, pack_rgbnet, pack_warp, unpack_rgbnet,
+                     unpack_warp)
+from .grid import channels_last_view
+
+
+class pose_model(torch.nn.Module):
+    """lib/voxurf_coarse.py:27-39"""
+
+    def __init__(self, i_train=[], camera_noise=0.05):
+        super().__init__()
+        self.i_train = i_train
+        self.camera_noise = camera_noise
+        self.se3_refine = torch.nn.Parameter(torch.zeros((len(self.i_train), 6), dtype=torch.float32))
+        self.se3_align_refine = torch.nn.Parameter(torch.zeros((1, 6), dtype=torch.float32))
+        se3_noise = torch.randn(len(i_train), 6) * self.camera_noise
+        self.pose_noise = _se3_to_SE3_host(se3_noise)
+
+
+def _se3_to_SE3_host(wu):
+    """Host (CPU) evaluation used once at construction for the constant pose noise (lib/camera.py:127-142)."""
+    w, u = wu.split([3, 3], dim=-1)
+    wx = camera.lie.skew_symmetric(w)
+    theta = w.norm(dim=-1)[..., None, None]
+    I = torch.eye(3)
+
+    def taylor(kind):
+        ans, denom = torch.zeros_like(theta), 1.
+        for i in range(11):
+            if kind == 0:
+                if i > 0:
+                    denom *= (2 * i) * (2 * i + 1)
+            elif kind == 1:
+                denom *= (2 * i + 1) * (2 * i + 2)
+            else:
+                denom *= (2 * i + 2) * (2 * i + 3)
+            ans = ans + (-1) ** i * theta ** (2 * i) / denom
+        return ans
+
+    A, B, C = taylor(0), taylor(1), taylor(2)
+    R = I + A * wx + B * wx @ wx
+    V = I + B * wx + C * wx @ wx
+    return torch.cat([R, V @ u[..., None]], dim=-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class _TotalVariation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v):
+        C, (X, Y, Z) = v.shape[1], v.shape[2:]
+        out = torch.zeros(1, device=v.device)
+        ops.grid_tv_value(channels_last_view(v), (X, Y, Z), C, out)
+        ctx.save_for_backward(v)
+        return (out / 3 / v.numel())[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (v,) = ctx.saved_tensors
+        C, (X, Y, Z) = v.shape[1], v.shape[2:]
+        gv = torch.zeros_like(v, memory_format=torch.channels_last_3d)
+        ops.grid_tv_grad(channels_last_view(v), (X, Y, Z), C, 1.0 / (3 * v.numel()), g.reshape(1).contiguous().float(),
+                         channels_last_view(gv))
+        return gv
+
+
+def total_variation(v, mask=None):
+    """lib/voxurf_coarse.py:1298-1313 for the live case (no nonempty mask)."""
+    if mask is not None:
+        raise NotImplementedError('masked total_variation: MaskCache is never constructed on the live path')
+    if not v[0].permute(1, 2, 3, 0).is_contiguous():
+        v = v.contiguous(memory_format=torch.channels_last_3d)
+    return _TotalVariation.apply(v)
+
+
+def ray_start_from_ids(ray_id, N):
+    """sorted ray_id[M] (int64/int32) -> exclusive prefix ray_start[N+1] int32 (replaces kernel.cu:607-636)."""
+    counts = torch.bincount(ray_id.long(), minlength=N)
+    rs = torch.zeros(N + 1, dtype=torch.int32, device=ray_id.device)
+    rs[1:] = counts.cumsum(0).int()
+    return rs
+
+
+class Alphas2Weights(torch.autograd.Function):
+    """lib/voxurf_coarse.py:1316-1332 over pp_alpha2weight_{fwd,bwd}."""
+
+    @staticmethod
+    def forward(ctx, alpha, ray_id, N):
+        alpha = alpha.contiguous().float()
+        M = alpha.shape[0]
+        rs = ray_start_from_ids(ray_id, N)
+        f = dict(device=alpha.device, dtype=torch.float32)
+        w, T, last = torch.empty(M, **f), torch.empty(M, **f), torch.empty(N, **f)
+        i_end = torch.empty(N, device=alpha.device, dtype=torch.int32)
+        ops.alpha2weight_fwd(alpha, rs, N, w, T, last, i_end)
+        ctx.save_for_backward(alpha, w, T, last, rs, i_end)
+        ctx.n_rays = N
+        return w, last
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_weights, grad_last):
+        alpha, w, T, last, rs, i_end = ctx.saved_tensors
+        g = torch.empty_like(alpha)
+        ops.alpha2weight_bwd(alpha, w, T, last, rs, i_end, ctx.n_rays, grad_weights.contiguous().float(),
+                             grad_last.contiguous().float(), g)
+        return g, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class _VoxurfRender(torch.autograd.Function):
+    """One autograd node for Voxurf.forward: inputs rays + every trainable tensor, outputs the render dict."""
+
+    @staticmethod
+    def forward(ctx, model, ws, inv_s, pe_w, rays_o, rays_d, viewdirs, k0, sdf_alpha, sdf_beta, *mlp):
+        core = model._core
+        flat = FlatParams(rays_o.device)
+        rg = [(mlp[2 * i], mlp[2 * i + 1]) for i in range(4)]
+        wp = [(mlp[8 + 2 * i], mlp[8 + 2 * i + 1]) for i in range(5)]
+        flat.load_reference(sdf_alpha, sdf_beta, rg, wp)
+        k0_cl = channels_last_view(k0)
+        sdf_g = model.sdf.grid.detach()[0, 0].contiguous()
+        core.forward(ws, k0_cl, sdf_g, flat.view('sdf_ab'), flat.view('rgbnet'), flat.view('warp'), inv_s, pe_w)
+        ctx.model, ctx.ws, ctx.flat, ctx.inv_s, ctx.pe_w = model, ws, flat, inv_s, pe_w
+        ctx.k0, ctx.sdf_g = k0, sdf_g
+        M = ws.M
+        depth = ws.t_min / rays_d.detach().norm(dim=-1) + ws.depth_acc
+        outs = (ws.rgb_marched, ws.alphainv_last, ws.cum_weights.unsqueeze(-1), ws.weights[:M], ws.alpha[:M], ws.rgb[:M],
+                depth, ws.gradient[:M], ws.sdf_deform[:M], ws.grad_deform[:M].reshape(M, 3, 3),
+                ws.warp_out[:M, 3:4])
+        return tuple(o.clone() for o in outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_rgbm, g_last, g_cw, g_w, g_alpha, g_rgb, g_depth, g_grad, g_sdfd, g_gdef, g_corr):
+        model, ws, flat = ctx.model, ctx.ws, ctx.flat
+        core, M, cap = model._core, ws.M, ws.cap
+        ws.alloc_backward()
+        dev = ws.rays_o.device
+
+        def padded(t, width=None):
+            """upstream [M,...] grad -> capacity-sized contiguous buffer"""
+            shape = (cap,) if width is None else (cap, width)
+            b = torch.zeros(shape, device=dev)
+            b[:M] = t.reshape(M, -1) if width else t.reshape(M)
+            return b
+
+        ws.g_rgbm.copy_(g_rgbm)
+        ws.g_last.copy_(g_last)
+        ws.g_cw.copy_(g_cw.reshape(-1))
+        g_depth = g_depth.contiguous().float()
+        gg = padded(g_grad, 3)
+
+        def add_gradient(w):
+            w.g_gradient.add_(gg)
+
+        k0_grad = torch.zeros_like(ctx.k0, memory_format=torch.channels_last_3d)
+        core.backward(ws, channels_last_view(ctx.k0), ctx.sdf_g, flat.view('sdf_ab'), flat.view('rgbnet'), flat.view('warp'),
+                      ctx.inv_s, ctx.pe_w, channels_last_view(k0_grad), flat.view('sdf_ab', 'grad'),
+                      flat.view('rgbnet', 'grad'), flat.view('warp', 'grad'), g_depth=g_depth, g_weights=padded(g_w),
+                      g_gradient_ext=add_gradient, g_sdf_deform=padded(g_sdfd), g_grad_deform=padded(g_gdef, 9),
+                      g_correction=padded(g_corr), g_alpha_ext=padded(g_alpha), g_rgb_ext=padded(g_rgb, 3))
+        go, gd, gv = (torch.empty_like(ws.rays_o) for _ in range(3))
+        ops.raygen_select_bwd(core.cfg.pp, None, None, None, 0, 0, True, ws.rays_o, ws.rays_d, ws.t_min, ws.ray_start,
+                              ws.g_pts, ws.step, ws.g_view_s, None, None, None, g_depth, go, gd, gv, None)
+        g = flat.export_grads()
+        mlp_grads = []
+        for W, b in g['rgbnet'] + g['warp']:
+            mlp_grads += [W.contiguous(), b.contiguous()]
+        return (None, None, None, None, go, gd, gv, k0_grad, g['sdf_alpha'], g['sdf_beta'], *mlp_grads)
+
+
+def _ws_alloc_backward(self):
+    if hasattr(self, 'g_alpha'):
+        return
+    f = dict(dtype=torch.float32, device=self.rays_o.device)
+    e, N, cap = torch.empty, self.N, self.cap
+    self.g_rgbm, self.g_last, self.g_cw = e(N, 3, **f), e(N, **f), e(N, **f)
+    self.g_alpha, self.g_rgb = e(cap, **f), e(cap, 3, **f)
+    self.g_feat = e(cap, ops.FEAT_LD, **f)
+    self.g_gradient, self.g_pts, self.g_view_s = e(cap, 3, **f), e(cap, 3, **f), e(cap, 3, **f)
+    self.g_warp_out = e(cap, 16, **f)
+    self.scratch = e(2, cap * 4, 128, **f)
+
+
+Workspace.alloc_backward = _ws_alloc_backward
+
+
+class _WarpNet(nn.Module):
+    """Parameter container with the reference's names: warp_network.progress and
+    warp_network.deform_net.net.net.{0..4}.0.{weight,bias} (lib/deformation/deform_net.py:12-31, modules.py:43-124)."""
+
+    def __init__(self, range_shape, hidden=128):
+        super().__init__()
+        self.progress = nn.Parameter(torch.tensor(0.))
+        self.output_range = float(np.asarray(range_shape).max())
+        dims = [3, hidden, hidden, hidden, hidden, 4]
+        layers = []
+        for i in range(5):
+            lin = nn.Linear(dims[i], dims[i + 1])
+            nn.init.kaiming_normal_(lin.weight, a=0.0, nonlinearity='relu', mode='fan_in')   # modules.py:136-139
+            layers.append(nn.Sequential(lin))
+        nn.init.zeros_(layers[-1][0].weight)                                                   # modules.py:166-171
+        nn.init.zeros_(layers[-1][0].bias)
+        fc = nn.Module()
+        fc.net = nn.Sequential(*layers)
+        bvp = nn.Module()
+        bvp.net = fc
+        self.deform_net = bvp
+
+    def linears(self):
+        return [seq[0] for seq in self.deform_net.net.net]
+
+
+class Voxurf(torch.nn.Module):
+    """lib/voxurf_coarse.py:45-1263 (constructor :49-229)."""
+
+    def __init__(self, xyz_min, xyz_max, num_voxels=0, num_voxels_base=0, alpha_init=None, nearest=False,
+                 mask_cache_path=None, fast_color_thres=0, rgbnet_dim=0, rgbnet_direct=False,
+                 rgbnet_full_implicit=False, rgbnet_depth=3, rgbnet_width=128, posbase_pe=5, viewbase_pe=4,
+                 geo_rgb_dim=3, grad_mode='interpolate', s_ratio=2000, s_start=0.2, s_learn=False, step_start=0,
+                 smooth_ksize=0, smooth_sigma=1, camera_noise=0., barf_c2f=None, i_train=[], N_iters=20000,
+                 flow_ckpt_path='', flow_backbone='', HW=[[512, 512]], sg_config=None, optimize_sdf=False,
+                 range_shape=None, rect_size=None, **kwargs):
+        super().__init__()
+        if not (rgbnet_dim == 12 and rgbnet_direct and rgbnet_depth == 4 and rgbnet_width == 128 and geo_rgb_dim == 3
+                and not rgbnet_full_implicit and smooth_ksize == 0 and not s_learn):
+            raise NotImplementedError('the HIP path implements the shipped e2e configuration: rgbnet_dim=12, '
+                                      'rgbnet_direct, depth 4, width 128, geo_rgb_dim=3, no smoothing, s_learn=False')
+        self.i_train, self.N_iters, self.camera_noise, self.barf_c2f = i_train, N_iters, camera_noise, barf_c2f
+        self.register_buffer('xyz_min', torch.Tensor(xyz_min))
+        self.register_buffer('xyz_max', torch.Tensor(xyz_max))
+        self.flow_ckpt_path, self.flow_backbone, self.HW = flow_ckpt_path, flow_backbone, HW
+        self.range_shape, self.rect_size, self.sg_config = range_shape, rect_size, sg_config
+        self.fast_color_thres, self.nearest = fast_color_thres, nearest
+        self.s_ratio, self.s_start, self.s_learn, self.step_start = s_ratio, s_start, s_learn, step_start
+        self.s_val = torch.ones(1) * s_start            # not a registered parameter on GPU (voxurf_coarse.py:94)
+        self.optimize_sdf = optimize_sdf
+        self.num_voxels_base = num_voxels_base
+        self.voxel_size_base = ((self.xyz_max - self.xyz_min).prod() / self.num_voxels_base).pow(1 / 3)
+        self.diagonal_length = torch.sqrt(torch.sum(self.xyz_max - self.xyz_min ** 2))   # sic (voxurf_coarse.py:102)
+        self.alpha_init = alpha_init
+        self.act_shift = np.log(1 / (1 - alpha_init) - 1)
+        self._set_grid_resolution(num_voxels)
+        self.progress = torch.nn.Parameter(torch.tensor(0.))
+        self.sdf_alpha = torch.nn.Parameter(torch.Tensor([10.0]))
+        self.sdf_beta = torch.nn.Parameter(torch.Tensor([2.0]))
+        self.warp_network = _WarpNet(range_shape)
+        self.sdf = grid.create_grid('DenseGrid', channels=1, world_size=self.world_size, xyz_min=self.xyz_min,
+                                    xyz_max=self.xyz_max)
+        for p in self.sdf.parameters():
+            p.requires_grad = False                      # frozen template (voxurf_coarse.py:136-138)
+        self.sdf.grid.data = self._cube_init(rect_size)
+        self.rgbnet_kwargs = {'rgbnet_dim': rgbnet_dim, 'rgbnet_direct': rgbnet_direct,
+                              'rgbnet_full_implicit': rgbnet_full_implicit, 'rgbnet_depth': rgbnet_depth,
+                              'rgbnet_width': rgbnet_width, 'posbase_pe': posbase_pe, 'viewbase_pe': viewbase_pe}
+        self.rgbnet_full_implicit, self.rgbnet_direct, self.geo_rgb_dim = rgbnet_full_implicit, rgbnet_direct, geo_rgb_dim
+        self.k0_dim = rgbnet_dim
+        self.k0 = grid.create_grid('DenseGrid', channels=self.k0_dim, world_size=self.world_size, xyz_min=self.xyz_min,
+                                   xyz_max=self.xyz_max)
+        self.register_buffer('posfreq', torch.FloatTensor([(2 ** i) for i in range(posbase_pe)]))
+        self.register_buffer('viewfreq', torch.FloatTensor([(2 ** i) for i in range(viewbase_pe)]))
+        dim0 = (3 + 3 * posbase_pe * 2) + (3 + 3 * viewbase_pe * 2) + self.k0_dim + geo_rgb_dim
+        self.rgbnet = nn.Sequential(
+            nn.Linear(dim0, rgbnet_width), nn.ReLU(inplace=True),
+            *[nn.Sequential(nn.Linear(rgbnet_width, rgbnet_width), nn.ReLU(inplace=True))
+              for _ in range(rgbnet_depth - 2)],
+            nn.Linear(rgbnet_width, 3))
+        nn.init.constant_(self.rgbnet[-1].bias, 0)
+        self.mask_cache_path, self.mask_cache_thres = mask_cache_path, 1e9
+        self.mask_cache = self.nonempty_mask = None
+        # frozen convs kept only for state_dict compatibility (voxurf_coarse.py:231-265)
+        self.grad_conv = nn.Conv3d(1, 3, (3, 3, 3), stride=1, padding=1, padding_mode='replicate')
+        self.tv_smooth_conv = nn.Conv3d(1, 1, (3, 3, 3), stride=1, padding=1, padding_mode='replicate')
+        for p in list(self.grad_conv.parameters()) + list(self.tv_smooth_conv.parameters()):
+            p.requires_grad = False
+        self.grad_mode = grad_mode
+        self._core = None
+
+    # ---- construction helpers -----------------------------------------------------------------------------
+    def _set_grid_resolution(self, num_voxels):
+        self.num_voxels = num_voxels
+        self.voxel_size = ((self.xyz_max - self.xyz_min).prod() / num_voxels).pow(1 / 3)
+        self.world_size = ((self.xyz_max - self.xyz_min) / self.voxel_size).long()
+        self.voxel_size_ratio = self.voxel_size / self.voxel_size_base
+
+    def _cube_init(self, rect_size):
+        from .params_init import cube_sdf
+        cfg = type('C', (), {})()
+        cfg.xyz_min, cfg.xyz_max = self.xyz_min.cpu().numpy(), self.xyz_max.cpu().numpy()
+        cfg.world_size = [int(v) for v in self.world_size.tolist()]
+        return cube_sdf(cfg, list(rect_size))
+
+    def _scene(self, render_kwargs):
+        key = (float(render_kwargs['stepsize']), float(render_kwargs['near']), float(render_kwargs['far']),
+               float(render_kwargs['bg']), int(self.num_voxels))
+        if self._core is None or self._core_key != key:
+            cfg = SceneConfig(self.xyz_min.cpu().numpy(), self.xyz_max.cpu().numpy(), int(self.num_voxels),
+                              stepsize=key[0], near=key[1], far=key[2], bg=key[3], N_iters=self.N_iters,
+                              s_ratio=self.s_ratio, s_start=self.s_start, step_start=self.step_start,
+                              barf_c2f=None if self.barf_c2f is None else tuple(self.barf_c2f),
+                              posbase_pe=self.rgbnet_kwargs['posbase_pe'], viewbase_pe=self.rgbnet_kwargs['viewbase_pe'],
+                              k0_dim=self.k0_dim, out_range=self.warp_network.output_range)
+            self._core, self._core_key = RenderCore(cfg), key
+        return self._core
+
+    def get_kwargs(self):
+        return {'xyz_min': self.xyz_min.cpu().numpy(), 'xyz_max': self.xyz_max.cpu().numpy(),
+                'num_voxels': self.num_voxels, 'num_voxels_base': self.num_voxels_base, 'alpha_init': self.alpha_init,
+                'nearest': self.nearest, 'mask_cache_path': self.mask_cache_path,
+                'mask_cache_thres': self.mask_cache_thres, 'fast_color_thres': self.fast_color_thres,
+                'geo_rgb_dim': self.geo_rgb_dim, 'flow_ckpt_path': self.flow_ckpt_path,
+                'flow_backbone': self.flow_backbone, 'sg_config': self.sg_config, 'HW': self.HW,
+                'i_train': self.i_train, 'N_iters': self.N_iters, 'camera_noise': self.camera_noise,
+                'range_shape': self.range_shape, 'rect_size': self.rect_size, **self.rgbnet_kwargs}
+
+    def get_MaskCache_kwargs(self):
+        return {'xyz_min': self.xyz_min.cpu().numpy(), 'xyz_max': self.xyz_max.cpu().numpy(),
+                'act_shift': self.act_shift, 'voxel_size_ratio': self.voxel_size_ratio, 'nearest': self.nearest}
+
+    @torch.no_grad()
+    def maskout_near_cam_vox(self, cam_o, near):
+        """voxurf_coarse.py:379-391 (writes sdf = 1 near the given points)."""
+        g = self.sdf.grid
+        xs = [torch.linspace(self.xyz_min[i], self.xyz_max[i], g.shape[2 + i], device=g.device) for i in range(3)]
+        xyz = torch.stack(torch.meshgrid(*xs, indexing='ij'), -1)
+        nearest = torch.stack([(xyz.unsqueeze(-2) - co).pow(2).sum(-1).sqrt().amin(-1) for co in cam_o.split(100)]).amin(0)
+        g[nearest[None, None] <= near] = 1
+
+    @torch.no_grad()
+    def scale_volume_grid(self, num_voxels):
+        self._set_grid_resolution(num_voxels)
+        self.sdf.scale_volume_grid(self.world_size)
+        if self.k0_dim > 0:
+            self.k0.scale_volume_grid(self.world_size)
+        self._core = None
+
+    def k0_total_variation(self, k0_tv=1., k0_grad_tv=0.):
+        if k0_grad_tv > 0:
+            raise NotImplementedError
+        return total_variation(self.k0.grid) if k0_tv > 0 else 0
+
+    # ---- parameter gathering ----------------------------------------------------------------------------------
+    def _mlp_tensors(self):
+        rg = [self.rgbnet[0], self.rgbnet[2][0], self.rgbnet[3][0], self.rgbnet[4]]
+        out = []
+        for lin in rg + self.warp_network.linears():
+            out += [lin.weight, lin.bias]
+        return out
+
+    def _set_progress(self, global_step):
+        v = 1. if global_step is None else global_step / self.N_iters
+        self.progress.data.fill_(v)
+        self.warp_network.progress.data.fill_(v)
+        return v
+
+    def _inv_s(self, global_step, is_train):
+        """neus_alpha_from_sdf_scatter's s_val bookkeeping (voxurf_coarse.py:485-495)."""
+        if is_train:
+            s_val = 1. / (global_step + self.s_ratio / self.s_start - self.step_start) * self.s_ratio
+            self.s_val = torch.ones(1) * s_val
+        else:
+            s_val = 0
+        inv_s = float((torch.ones(1) / self.s_val)[0])
+        return s_val, inv_s
+
+    def _check_inputs(self, *ts):
+        for t in ts:
+            if not t.is_cuda:
+                raise RuntimeError('poseprobe_amd.Voxurf runs on the HIP path only: inputs must be CUDA tensors')
+
+    # ---- sampling (API parity helpers) ------------------------------------------------------------------------
+    def _sample_dense(self, core, rays_o, rays_d, jitter):
+        cfg = core.cfg
+        N, S = rays_o.shape[0], cfg.n_samples
+        dev = rays_o.device
+        f, i = dict(device=dev, dtype=torch.float32), dict(device=dev, dtype=torch.int32)
+        sc = max(N * S, N)
+        buf = dict(t_min=torch.empty(N, **f), t_max=torch.empty(N, **f), ray_start=torch.zeros(N + 1, **i),
+                   count=torch.zeros(1, **i), pts=torch.empty(sc, 3, **f), ray_id=torch.empty(sc, **i),
+                   step_k=torch.empty(sc, **i), step=torch.empty(sc, **f),
+                   keep=torch.empty(N * S, device=dev, dtype=torch.uint8))
+        ops.sample_dense(cfg.pp, rays_o, rays_d, jitter, sc, buf['t_min'], buf['t_max'], buf['ray_start'], buf['count'],
+                         buf['pts'], buf['ray_id'], buf['step_k'], buf['step'], buf['keep'])
+        buf['M'] = int(buf['count'].item())     # the reference synchronises here too (boolean-mask compaction)
+        return buf
+
+    def sample_ray_ori(self, rays_o, rays_d, near, far, stepsize, is_train=False, jitter=None, **render_kwargs):
+        """Dense-layout outputs of the reference's sample_ray_ori (voxurf_coarse.py:697-719):
+        rays_pts[N,S,3], mask_outbbox[N,S], step[N,S], t_min[N], t_max[N] - reconstructed from the compacted sampler."""
+        core = self._scene(dict(near=near, far=far, stepsize=stepsize, bg=render_kwargs.get('bg', 0)))
+        self._check_inputs(rays_o, rays_d)
+        N, S = rays_o.shape[0], core.cfg.n_samples
+        if is_train and jitter is None:
+            jitter = torch.rand(N, device=rays_o.device)
+        b = self._sample_dense(core, rays_o.contiguous().float(), rays_d.contiguous().float(), jitter if is_train else None)
+        keep = b['keep'].bool().reshape(N, S)
+        rng = torch.arange(S, device=rays_o.device)[None].float().repeat(N, 1)
+        if is_train:
+            rng = rng + jitter.reshape(-1, 1)
+        step = stepsize * self.voxel_size.to(rays_o.device) * rng
+        interpx = b['t_min'][..., None] + step / rays_d.norm(dim=-1, keepdim=True)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
+        return pts, ~keep, step, b['t_min'], b['t_max']
+
+    # ---- forward ----------------------------------------------------------------------------------------------
+    def forward(self, rays_o, rays_d, viewdirs, use_deform=True, global_step=None, **render_kwargs):
+        """voxurf_coarse.py:922-1092.  Extension: render_kwargs['jitter'] ([N] in [0,1)) overrides the internally drawn
+        per-ray jitter (the reference draws it from the global CUDA generator, :713)."""
+        if not use_deform:
+            raise NotImplementedError('use_deform=False is never taken on the live path (recon_scene.py:603)')
+        if self.fast_color_thres > 0:
+            raise NotImplementedError('fast_color_thres > 0 (all shipped configs use 0)')
+        self._check_inputs(rays_o, rays_d, viewdirs)
+        core = self._scene(render_kwargs)
+        cfg = core.cfg
+        is_train = global_step is not None
+        progress = self._set_progress(global_step)
+        N = len(rays_o)
+        ro, rd, vd = rays_o.contiguous().float(), rays_d.contiguous().float(), viewdirs.contiguous().float()
+        jitter = None
+        if is_train:
+            jitter = render_kwargs.get('jitter')
+            jitter = torch.rand(N, device=ro.device) if jitter is None else jitter.to(ro.device).float().contiguous()
+        sb = self._sample_dense(core, ro.detach(), rd.detach(), jitter)
+        M = sb['M']
+        cap = max((M + 4095) // 4096 * 4096, 4096)
+        ws = Workspace(N, cap, ro.device, sample_capacity=sb['pts'].shape[0], backward=False)
+        ws.M = M
+        ws.rays_o, ws.rays_d, ws.viewdirs = ro.detach(), rd.detach(), vd.detach()
+        for k in ('t_min', 't_max', 'ray_start', 'count', 'pts', 'ray_id', 'step_k', 'step'):
+            setattr(ws, k, sb[k])
+        s_val, inv_s = self._inv_s(global_step, is_train)
+        pe_w = torch.from_numpy(cfg.pe_weights(progress)).to(ro.device)
+        self.k0.ensure_layout()
+        outs = _VoxurfRender.apply(self, ws, inv_s, pe_w, ro, rd, vd, self.k0.grid, self.sdf_alpha, self.sdf_beta,
+                                   *self._mlp_tensors())
+        (rgb_marched, alphainv_last, cum_weights, weights, alpha, rgb, depth, gradient, sdf_deform, grad_deform,
+         correction) = outs
+        normal_marched = None
+        if render_kwargs.get('render_grad', False):
+            normal = gradient.detach() / (gradient.detach().norm(2, -1, keepdim=True) + 1e-6)
+            normal_marched = torch.zeros(N, 3, device=ro.device).index_add_(0, ws.ray_id[:M].long(),
+                                                                             weights.detach().unsqueeze(-1) * normal)
+        return {
+            'alphainv_cum': alphainv_last, 'weights': weights, 'cum_weights': cum_weights, 'rgb_marched': rgb_marched,
+            'normal_marched': normal_marched, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth, 'disp': 1 / depth,
+            'mask': sb['keep'].bool(), 'mask_outbbox': torch.zeros(M, dtype=torch.bool, device=ro.device),
+            'gradient': gradient, 's_val': s_val, 'k0_tv': self.k0_total_variation(), 'sdf_deform': sdf_deform,
+            'grad_deform': grad_deform, 'sdf_correct': correction,
+        }
+
+    @torch.no_grad()
+    def inference(self, rays_o, rays_d, viewdirs, global_step=None, **render_kwargs):
+        """voxurf_coarse.py:1094-1222: variable-length sampler (sample_pts_on_rays semantics), forward chain only."""
+        self._check_inputs(rays_o, rays_d, viewdirs)
+        core = self._scene(render_kwargs)
+        cfg = core.cfg
+        is_train = global_step is not None
+        progress = self._set_progress(global_step)
+        N = len(rays_o)
+        dev = rays_o.device
+        ro, rd, vd = rays_o.contiguous().float(), rays_d.contiguous().float(), viewdirs.contiguous().float()
+        f, i = dict(device=dev, dtype=torch.float32), dict(device=dev, dtype=torch.int32)
+        sc = N * (cfg.n_samples + 2)
+        t_min, t_max, n_steps = torch.empty(N, **f), torch.empty(N, **f), torch.empty(N, **i)
+        ray_start, count = torch.zeros(N + 1, **i), torch.zeros(1, **i)
+        pts, ray_id, step_id = torch.empty(sc, 3, **f), torch.empty(sc, **i), torch.empty(sc, **i)
+        ops.sample_var(cfg.pp, ro, rd, sc, t_min, t_max, n_steps, ray_start, count, pts, ray_id, step_id)
+        M = int(count.item())
+        cap = max((M + 4095) // 4096 * 4096, 4096)
+        ws = Workspace(N, cap, dev, sample_capacity=sc, backward=False)
+        ws.M = M
+        ws.rays_o, ws.rays_d, ws.viewdirs = ro, rd, vd
+        ws.t_min, ws.t_max, ws.ray_start, ws.count, ws.pts, ws.ray_id, ws.step_k = t_min, t_max, ray_start, count, pts, ray_id, step_id
+        dist = float(np.float32(cfg.stepsize) * np.float32(cfg.voxel_size))
+        ws.step = step_id[:].float() * dist
+        s_val, inv_s = self._inv_s(global_step, is_train)
+        pe_w = torch.from_numpy(cfg.pe_weights(progress)).to(dev)
+        self.k0.ensure_layout()
+        flat = FlatParams(dev)
+        mlp = self._mlp_tensors()
+        flat.load_reference(self.sdf_alpha, self.sdf_beta, [(mlp[2 * k], mlp[2 * k + 1]) for k in range(4)],
+                            [(mlp[8 + 2 * k], mlp[8 + 2 * k + 1]) for k in range(5)])
+        core.forward(ws, channels_last_view(self.k0.grid), self.sdf.grid[0, 0].contiguous(), flat.view('sdf_ab'),
+                     flat.view('rgbnet'), flat.view('warp'), inv_s, pe_w)
+        gradient = ws.gradient[:M]
+        normal = gradient / (gradient.norm(2, -1, keepdim=True) + 1e-6)
+        weights = ws.weights[:M]
+        normal_marched = torch.zeros(N, 3, device=dev).index_add_(0, ray_id[:M].long(), weights.unsqueeze(-1) * normal)
+        depth = ws.depth_acc.clone()
+        return {
+            'alphainv_cum': ws.alphainv_last, 'weights': weights, 'cum_weights': ws.cum_weights.unsqueeze(-1),
+            'rgb_marched': ws.rgb_marched, 'normal_marched': normal_marched, 'raw_alpha': ws.alpha[:M],
+            'raw_rgb': ws.rgb[:M], 'depth': depth, 'disp': 1 / depth, 'mask': torch.ones_like(step_id[:M]).long(),
+            'mask_outbbox': None, 'gradient': gradient,
+            'gradient_error': ((torch.linalg.norm(gradient, ord=2, dim=-1) - 1.0) ** 2).mean(), 's_val': s_val,
+            'ray_id': ray_id[:M].long(), 'step_id': step_id[:M].long(),
+        }
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# rays (lib/voxurf_coarse.py:1339-1631)
+# ---------------------------------------------------------------------------------------------------------------
+class _RaysAtPixels(torch.autograd.Function):
+    """c2w[V,3,4] + flat pixel indices -> rays, differentiable w.r.t. c2w (pp_raygen_select_{fwd,bwd})."""
+
+    @staticmethod
+    def forward(ctx, c2w, ray_idx, intr, H, W, inverse_y, normalize):
+        N = ray_idx.shape[0]
+        dev = c2w.device
+        o, d, v = (torch.empty(N, 3, device=dev) for _ in range(3))
+        sc = ops.make_scene([0, 0, 0], [1, 1, 1], [2, 2, 2], 1.0, 1.0, 0., 1., 0.)
+        c2w_c = c2w.contiguous().float()
+        ops.raygen_select_fwd(sc, ray_idx, c2w_c, intr, H, W, inverse_y, normalize, None, None, o, d, v, None, None)
+        ctx.save_for_backward(c2w_c, ray_idx, intr, o, d)
+        ctx.meta = (H, W, inverse_y, normalize, sc)
+        return o, d, v
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go, gd, gv):
+        c2w, ray_idx, intr, o, d = ctx.saved_tensors
+        H, W, inverse_y, normalize, sc = ctx.meta
+        if not normalize:
+            raise NotImplementedError('pose gradients are implemented for the Voxurf ray variant (normalised rays_d)')
+        N, V = ray_idx.shape[0], c2w.shape[0]
+        dev = c2w.device
+        g = torch.zeros(V, 3, 4, device=dev)
+        zero_start = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+        dummy = torch.zeros(1, 3, device=dev)
+        # no samples: the kernel only projects the per-ray grads (rays_d and viewdirs are one tensor) onto c2w
+        ops.raygen_select_bwd(sc, ray_idx, c2w, intr, H, W, inverse_y, o, d, torch.zeros(N, device=dev), zero_start, dummy,
+                              torch.zeros(1, device=dev), None, go.contiguous().float(), gd.contiguous().float(),
+                              gv.contiguous().float(), None, None, None, None, g)
+        return g, None, None, None, None, None, None
+
+
+def _intr_of(K, device):
+    K = torch.as_tensor(np.asarray(K.detach().cpu() if isinstance(K, torch.Tensor) else K), dtype=torch.float32)
+    if K.dim() == 2:
+        K = K[None]
+    return torch.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], -1).to(device).contiguous()
+
+
+def get_rays(H, W, K, c2w, inverse_y, flip_x, flip_y, mode='center', normalize=False):
+    if mode != 'center':
+        raise NotImplementedError("only mode='center' is used on the live path")
+    dev = c2w.device
+    ii = torch.arange(W, device=dev)
+    jj = torch.arange(H, device=dev)
+    if flip_x:
+        ii = ii.flip(0)
+    if flip_y:
+        jj = jj.flip(0)
+    idx = (jj[:, None] * W + ii[None, :]).reshape(-1).int().contiguous()
+    o, d, v = _RaysAtPixels.apply(c2w[None, :3, :4], idx, _intr_of(K, dev), H, W, bool(inverse_y), normalize)
+    return o.reshape(H, W, 3), d.reshape(H, W, 3), v.reshape(H, W, 3)
+
+
+def get_rays_of_a_view(H, W, K, c2w, ndc, inverse_y, flip_x, flip_y, mode='center'):
+    """voxurf_coarse.py:1402-1407: rays_d = viewdirs = d/|d|."""
+    rays_o, rays_d, viewdirs = get_rays(H, W, K, c2w, inverse_y, flip_x, flip_y, mode, normalize=True)
+    if ndc:
+        rays_o, rays_d = ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
+    return rays_o, rays_d, viewdirs
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    o0 = -1. / (W / (2. * focal)) * rays_o[..., 0] / rays_o[..., 2]
+    o1 = -1. / (H / (2. * focal)) * rays_o[..., 1] / rays_o[..., 2]
+    o2 = 1. + 2. * near / rays_o[..., 2]
+    d0 = -1. / (W / (2. * focal)) * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
+    d1 = -1. / (H / (2. * focal)) * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
+    d2 = -2. * near / rays_o[..., 2]
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+
+
+def select_training_rays(ray_idx, rgb_tr_ori, mask_tr_ori, train_poses, HW, Ks, inverse_y=True):
+    """Index-first equivalent of get_training_rays_flatten(...)[indices] (voxurf_coarse.py:1518-1549 +
+    recon_scene.py:598-600): only the N selected pixels are generated instead of all V*H*W rays."""
+    H, W = int(HW[0][0]), int(HW[0][1])
+    dev = train_poses.device
+    idx = ray_idx.to(dev).int().contiguous()
+    o, d, v = _RaysAtPixels.apply(train_poses[:, :3, :4], idx, _intr_of(Ks, dev), H, W, bool(inverse_y), True)
+    rgb = rgb_tr_ori.reshape(-1, 3)[idx.long()]
+    mask = mask_tr_ori.reshape(-1, 1)[idx.long()]
+    return rgb, mask, o, d, v
+
+
+def get_training_rays_flatten(rgb_tr_ori, mask_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y):
+    """voxurf_coarse.py:1518-1549 (all V*H*W rays; kept for API parity - prefer select_training_rays)."""
+    assert len(rgb_tr_ori) == len(train_poses) and len(rgb_tr_ori) == len(Ks) and len(rgb_tr_ori) == len(HW)
+    ro, rd, vd, imsz = [], [], [], []
+    for c2w, img, (H, W), K in zip(train_poses, rgb_tr_ori, HW, Ks):
+        o, d, v = get_rays_of_a_view(int(H), int(W), K, c2w, ndc, inverse_y, flip_x, flip_y)
+        ro.append(o.flatten(0, 1)), rd.append(d.flatten(0, 1)), vd.append(v.flatten(0, 1))
+        imsz.append(int(H) * int(W))
+    rgb_tr = torch.cat([im.flatten(0, 1) for im in rgb_tr_ori])
+    mask_tr = torch.cat([m.flatten(0, 1) for m in mask_tr_ori])
+    return rgb_tr, mask_tr, torch.cat(ro), torch.cat(rd), torch.cat(vd), imsz
+
+
+def get_training_rays(rgb_tr, mask_tr, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y):
+    """voxurf_coarse.py:1494-1515"""
+    H, W = HW[0]
+    K = Ks[0]
+    outs = [get_rays_of_a_view(int(H), int(W), K, c2w, ndc, inverse_y, flip_x, flip_y) for c2w in train_poses]
+    return (rgb_tr, mask_tr, torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]),
+            torch.stack([o[2] for o in outs]), [1] * len(rgb_tr))
