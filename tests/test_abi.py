@@ -1,0 +1,66 @@
+"""CPU-only checks of the drop-in boundary: the shared library loads, exports every symbol include/poseprobe_hip.h
+declares (no compute calls - there is no GPU here), argument validation works, and the product never imports the
+oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from poseprobe_amd import _lib, build_ext
+    build_ext.build()
+    protos = _lib.parse_header()
+    assert len(protos) >= 27
+    L = ctypes.CDLL(_lib.SO_PATH)
+    for name in protos:
+        assert hasattr(L, name), f'{name} declared in the header but not exported'
+    assert hasattr(L, 'pp_last_error')
+    L2 = _lib.lib()
+    assert L2.pp_abi_version() == 1
+
+
+def test_pp_scene_struct_matches_header_layout():
+    from poseprobe_amd._lib import pp_scene
+    # 6 floats + 3 ints + 5 floats + int + float + 3 ints = 19 x 4 bytes, no padding
+    assert ctypes.sizeof(pp_scene) == 19 * 4
+    hdr = open(os.path.join(ROOT, 'include', 'poseprobe_hip.h')).read()
+    body = hdr[hdr.index('typedef struct {'):hdr.index('} pp_scene;')]
+    fields = re.findall(r'(?:float|int32_t)\s+(\w+)', body)
+    assert fields == [f[0] for f in pp_scene._fields_]
+
+
+def test_null_arguments_are_rejected_with_a_message():
+    from poseprobe_amd import _lib
+    L = _lib.lib()
+    rc = L.pp_pose_bwd(None, None, 3, None, None)
+    assert rc == -1
+    assert b'pp_pose_bwd' in L.pp_last_error()
+    with pytest.raises(_lib.PoseProbeError):
+        _lib.call('pp_pose_bwd', None, None, 3, None, None)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use it."""
+    pkg = os.path.join(ROOT, 'poseprobe_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in txt.replace('the oracle', '').replace('oracle)', '') or f == 'synthetic.py', \
+                    f'{f} mentions the oracle'
+    bench = open(os.path.join(ROOT, 'bench.py')).read()
+    uses = [l for l in bench.splitlines() if 'from oracle' in l or 'import oracle' in l]
+    assert len(uses) == 1 and 'voxurf_oracle' in uses[0]           # inside cpu_baseline() only
+    assert bench.index('def cpu_baseline') < bench.index(uses[0]) < bench.index('def main')
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from poseprobe_amd import ops
+    a = torch.zeros(4)
+    with pytest.raises(RuntimeError, match='CUDA'):
+        ops.alpha2weight_fwd(a, a, 1, a, a, a, a)

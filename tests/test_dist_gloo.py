@@ -1,0 +1,97 @@
+"""N>1 path on CPU: world_size-2 `gloo` rehearsal of the ray-sharded data-parallel step (poseprobe_amd.dist):
+reduce-scatter of the dense grid gradient along X, ZeRO-1 sharded TV+Adam, all-gather of the updated slabs and the
+single small all-reduce bucket.  The optimiser arithmetic here is the ORACLE's (no GPU in this container); what is
+under test is the sharding/collective choreography that bench.py --gpus N runs with RCCL."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tv_grad(k0, scale):
+    p = k0.clone().requires_grad_(True)
+    from oracle import voxurf_oracle as O
+    (O.total_variation(p.permute(3, 0, 1, 2)[None]) * scale).backward()
+    return p.grad
+
+
+def _worker(rank, world, port, X, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import voxurf_oracle as O
+    from poseprobe_amd.dist import DistContext, slab_bounds
+    ctx = DistContext()
+    g = torch.Generator().manual_seed(7)
+    Y, Z, C = 5, 4, 12
+    k0 = torch.randn(X, Y, Z, C, generator=g) * 0.1            # replicated parameters (channels-last)
+    m, v = torch.zeros_like(k0), torch.zeros_like(k0)
+    gr = torch.Generator().manual_seed(100 + rank)
+    grad_local = torch.randn(X, Y, Z, C, generator=gr) * 1e-3  # this rank's ray shard contributes a different gradient
+    small = [torch.randn(1000, generator=gr), torch.randn(3, 6, generator=gr)]
+    small_local = [t.clone() for t in small]
+    # ---- the choreography of TrainEngine.train_step
+    grad = grad_local.clone()
+    xb, xe = ctx.reduce_scatter_grid(grad)
+    assert (xb, xe) == slab_bounds(X, world, rank)
+    ctx.all_reduce_small(small)
+    scale = 1.0 / world
+    tv = _tv_grad(k0, 0.1 * 0.01)                               # rank invariant: never reduced
+    gtot = grad[xb:xe] * scale + tv[xb:xe]
+    O.adam_update(k0[xb:xe], gtot, m[xb:xe], v[xb:xe], 1, 0.1)
+    ctx.all_gather_grid(k0)
+    # ---- gather every rank's inputs on rank 0 for the single-process reference
+    gl = [torch.empty_like(grad_local) for _ in range(world)]
+    dist.all_gather(gl, grad_local)
+    sl = [torch.empty_like(small_local[0]) for _ in range(world)]
+    dist.all_gather(sl, small_local[0])
+    if rank == 0:
+        g0 = torch.Generator().manual_seed(7)
+        k_ref = torch.randn(X, Y, Z, C, generator=g0) * 0.1
+        m_ref, v_ref = torch.zeros_like(k_ref), torch.zeros_like(k_ref)
+        gsum = sum(gl) * scale + _tv_grad(k_ref, 0.1 * 0.01)
+        O.adam_update(k_ref, gsum, m_ref, v_ref, 1, 0.1)
+        ok = torch.allclose(k0, k_ref, rtol=1e-6, atol=1e-7) and torch.allclose(small[0], sum(sl), rtol=1e-6, atol=1e-6)
+        q.put(bool(ok))
+    # every rank must hold identical parameters after the gather
+    ks = [torch.empty_like(k0) for _ in range(world)]
+    dist.all_gather(ks, k0)
+    assert all(torch.equal(ks[0], k) for k in ks)
+    # outside its slab a rank's grad buffer is zero (ready for the next step's accumulation)
+    assert float(grad[:xb].abs().sum()) == 0 and float(grad[xe:].abs().sum()) == 0
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('X', [8, 6])
+def test_sharded_step_equals_single_process(X):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, X, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_slab_bounds_cover_grid():
+    from poseprobe_amd.dist import slab_bounds
+    for X, W in ((160, 8), (96, 4), (8, 2)):
+        cover = []
+        for r in range(W):
+            b, e = slab_bounds(X, W, r)
+            cover += list(range(b, e))
+        assert cover == list(range(X))
