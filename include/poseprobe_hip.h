@@ -171,7 +171,7 @@ int pp_color_feat_bwd(const pp_scene* sc, const float* k0_cl, const float* pts, 
 int pp_rgbnet_fwd(const float* params, const float* feat, const int32_t* count, int32_t capacity, float* acts,
                   float* rgb, void* stream);
 int pp_rgbnet_bwd(const float* params, const float* feat, const float* acts, const float* rgb,
-                  const float* rgb_grad, const int32_t* count, int32_t capacity, float* scratch /*[2][cap][128]*/,
+                  const float* rgb_grad, const int32_t* count, int32_t capacity, float* scratch /*[2][cap][128] + 49152*/,
                   float* params_grad /*atomic +=*/, float* feat_grad, void* stream);
 
 /* warp MLP (DeformedImplicitField, lib/deformation/deform_net.py:12-31, modules.py:43-124): 3->128x4->4 ReLU,
@@ -183,7 +183,7 @@ int pp_rgbnet_bwd(const float* params, const float* feat, const float* acts, con
 int pp_warp_fwd(const float* params, const float* pts, const int32_t* count, int32_t capacity, float out_range,
                 float* acts, float* out, void* stream);
 int pp_warp_bwd(const float* params, const float* pts, const float* acts, const float* out_grad,
-                const int32_t* count, int32_t capacity, float out_range, float* scratch /*[2][cap*4][128]*/,
+                const int32_t* count, int32_t capacity, float out_range, float* scratch /*[2][cap*4][128] + 49152*/,
                 float* params_grad /*atomic +=*/, float* pts_grad /* += */, void* stream);
 
 /* ---------------------------------------------------------------- losses: lib/losses.py:6-74 (object_losses),

@@ -30,7 +30,7 @@ def build(force=False, verbose=True):
     if not force and not is_stale():
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + sources() + ['-o', OUT]
+    cmd = [hipcc] + FLAGS + os.environ.get('PP_EXTRA_HIPCC_FLAGS', '').split() + sources() + ['-o', OUT]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

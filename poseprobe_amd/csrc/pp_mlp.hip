@@ -19,96 +19,34 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define LDT 33
-enum { MODE_NT = 0, MODE_NN = 1 };
+#define LDT 36   // row stride (floats): 16-B aligned rows, conflict-free ds_read_b128 / ds_write_b128
+enum { MODE_NT = 0 };
 enum { EPI_RELU = 0, EPI_MASK = 1, EPI_PLAIN = 2 };
 
-// C[r][n] = epi( sum_k A[r][k] * B(n,k) ),  NT: B(n,k) = W[n*ldw + k]   NN: B(n,k) = W[k*ldw + n]
-template <int MODE, int EPI, int COLS>
-__global__ __launch_bounds__(256) void k_gemm128(const float* __restrict__ A, int lda, const float* __restrict__ W,
-                                                 int ldw, int K, int Nout, const float* __restrict__ bias,
-                                                 const float* __restrict__ Xmask, int ldm, float* __restrict__ C,
-                                                 int ldc, const int32_t* __restrict__ count, int rmul, int rcap) {
-  __shared__ float As[128 * LDT];
-  __shared__ float Bs[128 * LDT];
-  const int R = min(count[0] * rmul, rcap);
-  const int r0 = blockIdx.x * 128;
-  if (r0 >= R) return;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wr = wid >> 1, wc = wid & 1;
-  const int l31 = lane & 31, lh = lane >> 5;
-  f32x16 acc[2][2];
+template <int EPI, int COLS, bool FULL, int TM>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][2], int r0, int R, int Nout, int wr, int wc, int l31,
+                                              int lh, const float* __restrict__ bias,
+                                              const float* __restrict__ Xmask, int ldm, float* __restrict__ C, int ldc) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
-
-  for (int k0 = 0; k0 < K; k0 += 32) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int e = tid + i * 256;
-      int row = e >> 3, c4 = e & 7;
-      int gr = r0 + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gr < R) v = *reinterpret_cast<const float4*>(A + (size_t)gr * lda + k0 + c4 * 4);
-      float* d = As + row * LDT + c4 * 4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    if (MODE == MODE_NT) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int e = tid + i * 256;
-        int n = e >> 3, c4 = e & 7;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < Nout) v = *reinterpret_cast<const float4*>(W + (size_t)n * ldw + k0 + c4 * 4);
-        float* d = Bs + n * LDT + c4 * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int e = tid + i * 256;
-        int kk = e >> 5, c4 = e & 31;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c4 * 4 < Nout) v = *reinterpret_cast<const float4*>(W + (size_t)(k0 + kk) * ldw + c4 * 4);
-        *reinterpret_cast<float4*>(Bs + kk * 128 + c4 * 4) = v;
-      }
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int kk = 0; kk < 32; kk += 2) {
-      const int kidx = kk + lh;
-      float a0 = As[(wr * 64 + l31) * LDT + kidx];
-      float a1 = As[(wr * 64 + 32 + l31) * LDT + kidx];
-      float b0, b1;
-      if (MODE == MODE_NT) {
-        b0 = Bs[(wc * 64 + l31) * LDT + kidx];
-        b1 = Bs[(wc * 64 + 32 + l31) * LDT + kidx];
-      } else {
-        b0 = Bs[kidx * 128 + wc * 64 + l31];
-        b1 = Bs[kidx * 128 + wc * 64 + 32 + l31];
-      }
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  // epilogue
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < TM; ++t) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int col = wc * 64 + u * 32 + l31;
-      if (col >= Nout) continue;
+      if (!FULL && col >= Nout) continue;
       const float bcol = (EPI == EPI_RELU && bias) ? bias[col] : 0.f;
+      const int rbase = r0 + wr * (32 * TM) + t * 32 + 4 * lh;
+      float mk[4] = {1.f, 1.f, 1.f, 1.f};
+      if (EPI == EPI_MASK && COLS == 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {          // one mask value per sample (4 rows): row of the primal activation
+          const int mrow = rbase + 8 * q;
+          mk[q] = (FULL || mrow < R) ? Xmask[(size_t)mrow * ldm + col] : 0.f;
+        }
+      }
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const int row = r0 + wr * 64 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-        if (row >= R) continue;
+        const int row = rbase + (reg & 3) + 8 * (reg >> 2);
+        if (!FULL && row >= R) continue;
         float val = acc[t][u][reg];
         if (EPI == EPI_RELU) {
           if (COLS == 1) {
@@ -119,13 +57,116 @@ __global__ __launch_bounds__(256) void k_gemm128(const float* __restrict__ A, in
             val = (y0 > 0.f) ? y : 0.f;
           }
         } else if (EPI == EPI_MASK) {
-          const int mrow = (COLS == 1) ? row : row - (reg & 3);
-          val = (Xmask[(size_t)mrow * ldm + col] > 0.f) ? val : 0.f;
+          if (COLS == 4) val = (mk[reg >> 2] > 0.f) ? val : 0.f;
+          else val = (Xmask[(size_t)row * ldm + col] > 0.f) ? val : 0.f;
         }
         C[(size_t)row * ldc + col] = val;
       }
     }
   }
+}
+
+// C[r][n] = epi( sum_k A[r][k] * B(n,k) ),  NT: B(n,k) = W[n*ldw + k]   NN: B(n,k) = W[k*ldw + n]
+template <int MODE, int EPI, int COLS, int BM>
+__global__ __launch_bounds__(256) void k_gemm128(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                 int ldw, int K, int Nout, const float* __restrict__ bias,
+                                                 const float* __restrict__ Xmask, int ldm, float* __restrict__ C,
+                                                 int ldc, const int32_t* __restrict__ count, int rmul, int rcap) {
+  constexpr int TM = BM / 64;            // 32-row MFMA tiles per wavefront (waves are arranged 2 x 2)
+  constexpr int NA = BM / 32;            // float4 of the A tile per thread and K-chunk
+  __shared__ float As[BM * LDT];
+  __shared__ float Bs[128 * LDT];
+  const int R = min(count[0] * rmul, rcap);
+  const int ntiles = (R + BM - 1) / BM;
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // Persistent work-group: tiles blockIdx.x, +gridDim.x, ...  Software pipeline: the global loads of the NEXT K-chunk -
+  // or of the next tile's first chunk - are issued before the MFMA block of the current chunk (register staging), so
+  // HBM/L2 latency hides behind the matrix pipe and the chip-wide load bursts of lock-stepped work-groups disappear.
+  float4 ra[NA], rw[4];
+  auto load_chunk = [&](int r0, int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int e = tid + i * 256;
+      int row = e >> 3, c4 = e & 7;
+      int gr = r0 + row;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < R) ra[i] = *reinterpret_cast<const float4*>(A + (size_t)gr * lda + k0 + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int e = tid + i * 256;
+      int row = e >> 3, c4 = e & 7;
+      rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < Nout) rw[i] = *reinterpret_cast<const float4*>(W + (size_t)row * ldw + k0 + c4 * 4);
+    }
+  };
+  load_chunk(tile * BM, 0);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int r0 = tile * BM;
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        int e = tid + i * 256;
+        *reinterpret_cast<float4*>(As + (e >> 3) * LDT + (e & 7) * 4) = ra[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int e = tid + i * 256;
+        *reinterpret_cast<float4*>(Bs + (e >> 3) * LDT + (e & 7) * 4) = rw[i];
+      }
+      __syncthreads();
+      if (k0 + 32 < K) load_chunk(r0, k0 + 32);
+      else if (tile + (int)gridDim.x < ntiles) load_chunk((tile + gridDim.x) * BM, 0);
+      // K-slot permutation: half-wave h supplies k = kb + 4h + j to the j-th of four consecutive MFMAs, so every lane
+      // fetches its four operands with ONE 16-byte LDS read (A and B use the same map, the sum over k is unchanged).
+#pragma unroll
+      for (int kb = 0; kb < 32; kb += 8) {
+        float4 a[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+          a[t] = *reinterpret_cast<const float4*>(As + (wr * (32 * TM) + t * 32 + l31) * LDT + kb + 4 * lh);
+        const float4 b0 = *reinterpret_cast<const float4*>(Bs + (wc * 64 + l31) * LDT + kb + 4 * lh);
+        const float4 b1 = *reinterpret_cast<const float4*>(Bs + (wc * 64 + 32 + l31) * LDT + kb + 4 * lh);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b0.x, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b1.x, acc[t][1], 0, 0, 0);
+          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b0.y, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b1.y, acc[t][1], 0, 0, 0);
+          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b0.z, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b1.z, acc[t][1], 0, 0, 0);
+          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b0.w, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b1.w, acc[t][1], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+    // epilogue.  Full tiles (all but the last one) take a branch-free instantiation.
+    if ((r0 + BM <= R) && (Nout == 128))
+      gemm_epilogue<EPI, COLS, true, TM>(acc, r0, R, Nout, wr, wc, l31, lh, bias, Xmask, ldm, C, ldc);
+    else
+      gemm_epilogue<EPI, COLS, false, TM>(acc, r0, R, Nout, wr, wc, l31, lh, bias, Xmask, ldm, C, ldc);
+  }
+}
+
+// dst[c][r] = src[r][c]  (weights are tiny: 128x128 / 128x64); lets the backward-data GEMM run in the same NT form
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  int c = i / rows, r = i - c * rows;           // consecutive threads write consecutive dst elements
+  dst[i] = src[r * cols + c];
 }
 
 // Wbar[n][k] += sum_r Y[r][n] * X[r][k]   (n < 128, k < Kx) ;  bbar[n] += sum_{r % COLS == 0} Y[r][n]
@@ -153,21 +194,32 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ Y, co
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
   float bsum = 0.f;
   const int kx4 = Kx >> 2;
-  for (int r0 = rb; r0 < re; r0 += 32) {
+  float4 ry[4], rx[4];
+  auto load_rows = [&](int r0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int e = tid + i * 256;
       int rr = e >> 5, c4 = e & 31;
       int gr = r0 + rr;
-      float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vx = vy;
+      ry[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rx[i] = ry[i];
       if (gr < re) {
-        vy = *reinterpret_cast<const float4*>(Y + (size_t)gr * 128 + c4 * 4);
-        if (c4 < kx4) vx = *reinterpret_cast<const float4*>(X + (size_t)gr * ldx + c4 * 4);
+        ry[i] = *reinterpret_cast<const float4*>(Y + (size_t)gr * 128 + c4 * 4);
+        if (c4 < kx4) rx[i] = *reinterpret_cast<const float4*>(X + (size_t)gr * ldx + c4 * 4);
       }
-      *reinterpret_cast<float4*>(Ys + rr * 128 + c4 * 4) = vy;
-      *reinterpret_cast<float4*>(Xs + rr * 128 + c4 * 4) = vx;
+    }
+  };
+  load_rows(rb);
+  for (int r0 = rb; r0 < re; r0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int e = tid + i * 256;
+      int rr = e >> 5, c4 = e & 31;
+      *reinterpret_cast<float4*>(Ys + rr * 128 + c4 * 4) = ry[i];
+      *reinterpret_cast<float4*>(Xs + rr * 128 + c4 * 4) = rx[i];
     }
     __syncthreads();
+    if (r0 + 32 < re) load_rows(r0 + 32);
     if (active) {
 #pragma unroll 4
       for (int kk = 0; kk < 32; kk += 2) {
@@ -288,40 +340,52 @@ __global__ __launch_bounds__(256) void k_warp_l4_bwd(const float* __restrict__ W
   if (j < 4 && bacc != 0.f) atomicAdd(&b4bar[j], bacc);
 }
 
-// backward of warp layer 0: consumes Ybar1 (already masked), produces W0bar[128,3], b0bar[128], pts_grad += .
-__global__ __launch_bounds__(256) void k_warp_l0_bwd(const float* __restrict__ W0, const float* __restrict__ pts,
-                                                     const float* __restrict__ Ybar, const int32_t* __restrict__ count,
-                                                     int capacity, float* __restrict__ W0bar, float* __restrict__ b0bar,
-                                                     float* __restrict__ pts_grad) {
-  __shared__ float red[4 * 128];
-  __shared__ float pred[4][3];
+// backward of warp layer 0, part (a): pts_grad[m][i] += sum_j Ybar1[4m][j] * W0[j][i]   (16 lanes per sample)
+__global__ __launch_bounds__(256) void k_warp_l0_bwd_pts(const float* __restrict__ W0, const float* __restrict__ Ybar,
+                                                         const int32_t* __restrict__ count, int capacity,
+                                                         float* __restrict__ pts_grad) {
   int M = min(count[0], capacity);
-  int m0 = blockIdx.x * STRIP;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int m = t >> 4, sub = t & 15;
+  bool live = m < M;
+  float acc[3] = {0.f, 0.f, 0.f};
+  if (live) {
+    const float4* yp = reinterpret_cast<const float4*>(Ybar + (size_t)m * 4 * 128 + sub * 8);
+    float4 ya = yp[0], yb = yp[1];
+    float y[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float* w = W0 + (sub * 8 + q) * 3;
+      acc[0] += y[q] * w[0]; acc[1] += y[q] * w[1]; acc[2] += y[q] * w[2];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float v = acc[i];
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+    if (live && sub == 0) pts_grad[m * 3 + i] += v;
+  }
+}
+
+// part (b): W0bar[j][i] += sum_m (Ybar1[4m][j] p_i + Ybar1[4m+1+i][j]) ; b0bar[j] += sum_m Ybar1[4m][j]
+#define STRIP0 128
+__global__ __launch_bounds__(256) void k_warp_l0_bwd_w(const float* __restrict__ pts, const float* __restrict__ Ybar,
+                                                       const int32_t* __restrict__ count, int capacity,
+                                                       float* __restrict__ W0bar, float* __restrict__ b0bar) {
+  __shared__ float red[4 * 128];
+  int M = min(count[0], capacity);
+  int m0 = blockIdx.x * STRIP0;
   if (m0 >= M) return;
   int h = threadIdx.x >> 7, j = threadIdx.x & 127;
-  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  float w[3] = {W0[j * 3], W0[j * 3 + 1], W0[j * 3 + 2]};
   float wacc[3] = {0, 0, 0}, bacc = 0.f;
-  int mend = min(m0 + STRIP, M);
-  for (int mm = m0; mm < mend; mm += 2) {
-    int m = mm + h;
-    bool live = m < mend;
-    float y0 = 0.f, pb[3] = {0, 0, 0};
-    if (live) {
-      size_t base = (size_t)m * 4 * 128 + j;
-      y0 = Ybar[base];
-      float p0 = pts[m * 3], p1 = pts[m * 3 + 1], p2 = pts[m * 3 + 2];
-      wacc[0] += y0 * p0 + Ybar[base + 128];
-      wacc[1] += y0 * p1 + Ybar[base + 256];
-      wacc[2] += y0 * p2 + Ybar[base + 384];
-      bacc += y0;
-      pb[0] = y0 * w[0]; pb[1] = y0 * w[1]; pb[2] = y0 * w[2];
-    }
-    for (int i = 0; i < 3; ++i) pb[i] = pp_wave_sum(pb[i]);
-    if (lane == 0) { pred[wid][0] = pb[0]; pred[wid][1] = pb[1]; pred[wid][2] = pb[2]; }
-    __syncthreads();
-    if (live && j < 3) pts_grad[m * 3 + j] += pred[h * 2][j] + pred[h * 2 + 1][j];
-    __syncthreads();
+  int mend = min(m0 + STRIP0, M);
+  for (int m = m0 + h; m < mend; m += 2) {
+    size_t base = (size_t)m * 4 * 128 + j;
+    float y0 = Ybar[base];
+    wacc[0] += y0 * pts[m * 3] + Ybar[base + 128];
+    wacc[1] += y0 * pts[m * 3 + 1] + Ybar[base + 256];
+    wacc[2] += y0 * pts[m * 3 + 2] + Ybar[base + 384];
+    bacc += y0;
   }
   if (h == 1) { for (int i = 0; i < 3; ++i) red[i * 128 + j] = wacc[i]; red[3 * 128 + j] = bacc; }
   __syncthreads();
@@ -408,6 +472,11 @@ __global__ __launch_bounds__(256) void k_rgb_out_bwd(const float* __restrict__ W
 #define WP_B4 (WP_W4 + 4 * 128)
 
 static const int TN_ROWS = 512;
+static const int GEMM_MAX_WG = 256 * 5;     // 5 resident work-groups per CU at BM=64 (25 KB LDS, 90 regs)
+static inline int gemm_grid(int rows, int bm) { int t = pp_div_up(rows, bm); return t < GEMM_MAX_WG ? t : GEMM_MAX_WG; }
+#ifndef PP_GEMM_BM
+#define PP_GEMM_BM 64
+#endif
 
 extern "C" int pp_rgbnet_fwd(const float* params, const float* feat, const int32_t* count, int32_t capacity,
                              float* acts, float* rgb, void* stream) {
@@ -415,12 +484,12 @@ extern "C" int pp_rgbnet_fwd(const float* params, const float* feat, const int32
   PP_REQUIRE(capacity > 0, "capacity<=0");
   hipStream_t st = pp_stream(stream);
   const size_t LS = (size_t)capacity * 128;
-  dim3 g(pp_div_up(capacity, 128)), b(256);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1>), g, b, 0, st, feat, 64, params + RG_W0, 64, 64, 128,
+  dim3 g(gemm_grid(capacity, PP_GEMM_BM)), b(256);
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1, PP_GEMM_BM>), g, b, 0, st, feat, 64, params + RG_W0, 64, 64, 128,
                      params + RG_B0, nullptr, 0, acts, 128, count, 1, capacity);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1>), g, b, 0, st, acts, 128, params + RG_W1, 128, 128, 128,
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1, PP_GEMM_BM>), g, b, 0, st, acts, 128, params + RG_W1, 128, 128, 128,
                      params + RG_B1, nullptr, 0, acts + LS, 128, count, 1, capacity);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1>), g, b, 0, st, acts + LS, 128, params + RG_W2, 128, 128, 128,
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1, PP_GEMM_BM>), g, b, 0, st, acts + LS, 128, params + RG_W2, 128, 128, 128,
                      params + RG_B2, nullptr, 0, acts + 2 * LS, 128, count, 1, capacity);
   hipLaunchKernelGGL(k_rgb_out_fwd, dim3(pp_div_up(capacity * 16, 256)), b, 0, st, params + RG_W3, params + RG_B3,
                      acts + 2 * LS, count, capacity, rgb);
@@ -437,23 +506,27 @@ extern "C" int pp_rgbnet_bwd(const float* params, const float* feat, const float
   const size_t LS = (size_t)capacity * 128;
   float* s0 = scratch;
   float* s1 = scratch + LS;
-  dim3 g(pp_div_up(capacity, 128)), gt(pp_div_up(capacity, TN_ROWS)), b(256);
+  dim3 g(gemm_grid(capacity, PP_GEMM_BM)), gt(pp_div_up(capacity, TN_ROWS)), b(256);
   hipLaunchKernelGGL(k_rgb_out_bwd, dim3(pp_div_up(capacity, STRIP)), b, 0, st, params + RG_W3, acts + 2 * LS, rgb,
                      rgb_grad, count, capacity, s0, params_grad + RG_W3, params_grad + RG_B3);
+  float* wt = scratch + 2 * LS;          // transposed weights W2^T, W1^T, W0^T
+  hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + RG_W2, wt, 128, 128);
+  hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + RG_W1, wt + 16384, 128, 128);
+  hipLaunchKernelGGL(k_transpose, dim3(32), b, 0, st, params + RG_W0, wt + 32768, 128, 64);
   // layer 2
   hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, s0, acts + LS, 128, 128, params_grad + RG_W2, 128,
                      params_grad + RG_B2, count, 1, capacity, TN_ROWS);
-  hipLaunchKernelGGL((k_gemm128<MODE_NN, EPI_MASK, 1>), g, b, 0, st, s0, 128, params + RG_W2, 128, 128, 128, nullptr,
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 1, PP_GEMM_BM>), g, b, 0, st, s0, 128, wt, 128, 128, 128, nullptr,
                      acts + LS, 128, s1, 128, count, 1, capacity);
   // layer 1
   hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, s1, acts, 128, 128, params_grad + RG_W1, 128, params_grad + RG_B1,
                      count, 1, capacity, TN_ROWS);
-  hipLaunchKernelGGL((k_gemm128<MODE_NN, EPI_MASK, 1>), g, b, 0, st, s1, 128, params + RG_W1, 128, 128, 128, nullptr,
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 1, PP_GEMM_BM>), g, b, 0, st, s1, 128, wt + 16384, 128, 128, 128, nullptr,
                      acts, 128, s0, 128, count, 1, capacity);
   // layer 0
   hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, s0, feat, 64, 64, params_grad + RG_W0, 64, params_grad + RG_B0,
                      count, 1, capacity, TN_ROWS);
-  hipLaunchKernelGGL((k_gemm128<MODE_NN, EPI_PLAIN, 1>), g, b, 0, st, s0, 128, params + RG_W0, 64, 128, 64, nullptr,
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_PLAIN, 1, PP_GEMM_BM>), g, b, 0, st, s0, 128, wt + 32768, 128, 128, 64, nullptr,
                      nullptr, 0, feat_grad, 64, count, 1, capacity);
   PP_CHECK_LAUNCH();
   return PP_OK;
@@ -466,14 +539,14 @@ extern "C" int pp_warp_fwd(const float* params, const float* pts, const int32_t*
   hipStream_t st = pp_stream(stream);
   const int rcap = capacity * 4;
   const size_t LS = (size_t)rcap * 128;
-  dim3 g(pp_div_up(rcap, 128)), b(256);
+  dim3 g(gemm_grid(rcap, PP_GEMM_BM)), b(256);
   hipLaunchKernelGGL(k_warp_l0_fwd, dim3(pp_div_up(capacity, 2)), b, 0, st, params + WP_W0, params + WP_B0, pts, count,
                      capacity, acts);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 4>), g, b, 0, st, acts, 128, params + WP_W1, 128, 128, 128,
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 4, PP_GEMM_BM>), g, b, 0, st, acts, 128, params + WP_W1, 128, 128, 128,
                      params + WP_B1, nullptr, 0, acts + LS, 128, count, 4, rcap);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 4>), g, b, 0, st, acts + LS, 128, params + WP_W2, 128, 128, 128,
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 4, PP_GEMM_BM>), g, b, 0, st, acts + LS, 128, params + WP_W2, 128, 128, 128,
                      params + WP_B2, nullptr, 0, acts + 2 * LS, 128, count, 4, rcap);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 4>), g, b, 0, st, acts + 2 * LS, 128, params + WP_W3, 128, 128, 128,
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 4, PP_GEMM_BM>), g, b, 0, st, acts + 2 * LS, 128, params + WP_W3, 128, 128, 128,
                      params + WP_B3, nullptr, 0, acts + 3 * LS, 128, count, 4, rcap);
   hipLaunchKernelGGL(k_warp_l4_fwd, dim3(pp_div_up(capacity, 4)), b, 0, st, params + WP_W4, params + WP_B4,
                      acts + 3 * LS, count, capacity, out_range, out);
@@ -491,27 +564,33 @@ extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* a
   const size_t LS = (size_t)rcap * 128;
   float* s0 = scratch;
   float* s1 = scratch + LS;
-  dim3 g(pp_div_up(rcap, 128)), gt(pp_div_up(rcap, TN_ROWS)), b(256);
+  dim3 g(gemm_grid(rcap, PP_GEMM_BM)), gt(pp_div_up(rcap, TN_ROWS)), b(256);
   hipLaunchKernelGGL(k_warp_l4_bwd, dim3(pp_div_up(capacity, STRIP)), b, 0, st, params + WP_W4, acts + 3 * LS, out_grad,
                      count, capacity, out_range, s0, params_grad + WP_W4, params_grad + WP_B4);
+  float* wt = scratch + 2 * LS;          // transposed weights W3^T, W2^T, W1^T
+  hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + WP_W3, wt, 128, 128);
+  hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + WP_W2, wt + 16384, 128, 128);
+  hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + WP_W1, wt + 32768, 128, 128);
   // layer 3
   hipLaunchKernelGGL((k_gemm_tn<4>), gt, b, 0, st, s0, acts + 2 * LS, 128, 128, params_grad + WP_W3, 128,
                      params_grad + WP_B3, count, 4, rcap, TN_ROWS);
-  hipLaunchKernelGGL((k_gemm128<MODE_NN, EPI_MASK, 4>), g, b, 0, st, s0, 128, params + WP_W3, 128, 128, 128, nullptr,
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 4, PP_GEMM_BM>), g, b, 0, st, s0, 128, wt, 128, 128, 128, nullptr,
                      acts + 2 * LS, 128, s1, 128, count, 4, rcap);
   // layer 2
   hipLaunchKernelGGL((k_gemm_tn<4>), gt, b, 0, st, s1, acts + LS, 128, 128, params_grad + WP_W2, 128,
                      params_grad + WP_B2, count, 4, rcap, TN_ROWS);
-  hipLaunchKernelGGL((k_gemm128<MODE_NN, EPI_MASK, 4>), g, b, 0, st, s1, 128, params + WP_W2, 128, 128, 128, nullptr,
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 4, PP_GEMM_BM>), g, b, 0, st, s1, 128, wt + 16384, 128, 128, 128, nullptr,
                      acts + LS, 128, s0, 128, count, 4, rcap);
   // layer 1
   hipLaunchKernelGGL((k_gemm_tn<4>), gt, b, 0, st, s0, acts, 128, 128, params_grad + WP_W1, 128, params_grad + WP_B1,
                      count, 4, rcap, TN_ROWS);
-  hipLaunchKernelGGL((k_gemm128<MODE_NN, EPI_MASK, 4>), g, b, 0, st, s0, 128, params + WP_W1, 128, 128, 128, nullptr,
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 4, PP_GEMM_BM>), g, b, 0, st, s0, 128, wt + 32768, 128, 128, 128, nullptr,
                      acts, 128, s1, 128, count, 4, rcap);
   // layer 0
-  hipLaunchKernelGGL(k_warp_l0_bwd, dim3(pp_div_up(capacity, STRIP)), b, 0, st, params + WP_W0, pts, s1, count, capacity,
-                     params_grad + WP_W0, params_grad + WP_B0, pts_grad);
+  hipLaunchKernelGGL(k_warp_l0_bwd_pts, dim3(pp_div_up(capacity * 16, 256)), b, 0, st, params + WP_W0, s1, count, capacity,
+                     pts_grad);
+  hipLaunchKernelGGL(k_warp_l0_bwd_w, dim3(pp_div_up(capacity, STRIP0)), b, 0, st, pts, s1, count, capacity,
+                     params_grad + WP_W0, params_grad + WP_B0);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }

@@ -3,6 +3,8 @@
 // streaming pass: reads p,g,m,v (+ 6 neighbours of p, cache-served), writes p',m,v and g=0 : 384 B/voxel at C=12
 // instead of the reference's separate TV forward, TV backward, zero_grad and Adam passes (528 B/voxel).
 // Parameters ping-pong between two buffers so that neighbour reads never see updated values.
+#include <stdlib.h>
+
 #include "pp_common.h"
 
 __device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : (x < 0.f ? -1.f : 0.f); }
@@ -21,50 +23,72 @@ __device__ __forceinline__ float adam1(float p, float g, float& m, float& v, flo
   return p - step_size * (m / denom);
 }
 
-// one thread = one float4 (4 channels of one voxel); q4 = C/4 float4 per voxel
+// X-marching formulation.  A thread owns one float4 column position (y,z,q) of the plane and walks a chunk of
+// x-planes keeping p[x-1], p[x], p[x+1] in registers: every parameter element is fetched from HBM exactly once (plus a
+// two-plane halo per chunk); the +-y / +-z neighbours are re-read from the plane currently being swept, which is L1/L2
+// resident because all tiles of a chunk run on ONE XCD (chunk = blockIdx % n_chunks, n_chunks a multiple of 8, and
+// blocks are dealt round-robin over the 8 XCDs).  g / m / v and the outputs are touched once: non-temporal accesses
+// keep them from evicting the parameter planes out of L2.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldnt4(const float4* p) {
+  v4f r = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  return make_float4(r.x, r.y, r.z, r.w);
+}
+__device__ __forceinline__ void stnt4(float4* p, float4 v) {
+  v4f r = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(p));
+}
+__device__ __forceinline__ void acc_sgn(float4& tv, float4 p, float4 n) {
+  tv.x += sgnf(p.x - n.x); tv.y += sgnf(p.y - n.y); tv.z += sgnf(p.z - n.z); tv.w += sgnf(p.w - n.w);
+}
+
 __global__ __launch_bounds__(256) void k_grid_tv_adam(const float4* __restrict__ p_in, float4* __restrict__ p_out,
                                                       float4* __restrict__ grad, float4* __restrict__ m_,
                                                       float4* __restrict__ v_, int X, int Y, int Z, int q4,
-                                                      int x_begin, int x_end, float tv_scale, float grad_scale,
-                                                      float b1, float b2, float eps, float step_size,
-                                                      float inv_sqrt_bc2, float* __restrict__ tv_out) {
+                                                      int x_begin, int x_end, int n_chunks, int chunk_len,
+                                                      float tv_scale, float grad_scale, float b1, float b2, float eps,
+                                                      float step_size, float inv_sqrt_bc2, float* __restrict__ tv_out) {
   __shared__ float sm[4];
-  const long long n_slab = (long long)(x_end - x_begin) * Y * Z * q4;
-  // XCD-aware placement: blocks that share an XCD (same blockIdx % 8) sweep one contiguous eighth of the slab, so the
-  // +-x / +-y neighbour planes a block touches were (or will be) streamed through the SAME XCD's L2.
-  const int nb = gridDim.x;
-  const int per = (nb + 7) / 8;
-  const int bid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  long long e = (long long)bid * 256 + threadIdx.x;
+  const int plane = Y * Z * q4;                      // float4 per x-plane
+  const int chunk = blockIdx.x % n_chunks;
+  const int tile = blockIdx.x / n_chunks;
+  const int i = tile * 256 + threadIdx.x;            // position inside the plane
+  const int xs = x_begin + chunk * chunk_len;
+  const int xe = min(xs + chunk_len, x_end);
   float tv_local = 0.f;
-  if (bid < nb && e < n_slab) {
-    e += (long long)x_begin * Y * Z * q4;
-    long long vox = e / q4;
-    int z = (int)(vox % Z);
-    long long t = vox / Z;
-    int y = (int)(t % Y);
-    int x = (int)(t / Y);
-    const long long sz = q4, sy = (long long)Z * q4, sx = (long long)Y * Z * q4;
-    float4 p = p_in[e];
-    float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (z > 0) { float4 s = sgn4(p, p_in[e - sz]); tv.x += s.x; tv.y += s.y; tv.z += s.z; tv.w += s.w; }
-    if (y > 0) { float4 s = sgn4(p, p_in[e - sy]); tv.x += s.x; tv.y += s.y; tv.z += s.z; tv.w += s.w; }
-    if (x > 0) { float4 s = sgn4(p, p_in[e - sx]); tv.x += s.x; tv.y += s.y; tv.z += s.z; tv.w += s.w; }
-    if (z < Z - 1) { float4 nbv = p_in[e + sz]; float4 s = sgn4(p, nbv); tv.x += s.x; tv.y += s.y; tv.z += s.z; tv.w += s.w; tv_local += abs4(p, nbv); }
-    if (y < Y - 1) { float4 nbv = p_in[e + sy]; float4 s = sgn4(p, nbv); tv.x += s.x; tv.y += s.y; tv.z += s.z; tv.w += s.w; tv_local += abs4(p, nbv); }
-    if (x < X - 1) { float4 nbv = p_in[e + sx]; float4 s = sgn4(p, nbv); tv.x += s.x; tv.y += s.y; tv.z += s.z; tv.w += s.w; tv_local += abs4(p, nbv); }
-    float4 g = grad[e], m = m_[e], v = v_[e];
-    g.x = g.x * grad_scale + tv_scale * tv.x; g.y = g.y * grad_scale + tv_scale * tv.y;
-    g.z = g.z * grad_scale + tv_scale * tv.z; g.w = g.w * grad_scale + tv_scale * tv.w;
-    float4 o;
-    o.x = adam1(p.x, g.x, m.x, v.x, b1, b2, eps, step_size, inv_sqrt_bc2);
-    o.y = adam1(p.y, g.y, m.y, v.y, b1, b2, eps, step_size, inv_sqrt_bc2);
-    o.z = adam1(p.z, g.z, m.z, v.z, b1, b2, eps, step_size, inv_sqrt_bc2);
-    o.w = adam1(p.w, g.w, m.w, v.w, b1, b2, eps, step_size, inv_sqrt_bc2);
-    p_out[e] = o;
-    m_[e] = m;
-    v_[e] = v;
-    grad[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < plane && xs < xe) {
+    const int vox = i / q4;
+    const int z = vox % Z, y = vox / Z;
+    const int sz = q4, sy = Z * q4;
+    const bool zl = z > 0, zh = z < Z - 1, yl = y > 0, yh = y < Y - 1;
+    size_t e = (size_t)xs * plane + i;
+    float4 pm = make_float4(0.f, 0.f, 0.f, 0.f), pc = p_in[e], pn;
+    if (xs > 0) pm = p_in[e - plane];
+    for (int x = xs; x < xe; ++x, e += plane) {
+      const bool xh = x < X - 1;
+      pn = xh ? p_in[e + plane] : pc;
+      float4 g = ldnt4(grad + e), m = ldnt4(m_ + e), v = ldnt4(v_ + e);
+      float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x > 0) acc_sgn(tv, pc, pm);
+      if (xh) { acc_sgn(tv, pc, pn); tv_local += abs4(pc, pn); }
+      if (zl) acc_sgn(tv, pc, p_in[e - sz]);
+      if (yl) acc_sgn(tv, pc, p_in[e - sy]);
+      if (zh) { float4 nb = p_in[e + sz]; acc_sgn(tv, pc, nb); tv_local += abs4(pc, nb); }
+      if (yh) { float4 nb = p_in[e + sy]; acc_sgn(tv, pc, nb); tv_local += abs4(pc, nb); }
+      g.x = g.x * grad_scale + tv_scale * tv.x; g.y = g.y * grad_scale + tv_scale * tv.y;
+      g.z = g.z * grad_scale + tv_scale * tv.z; g.w = g.w * grad_scale + tv_scale * tv.w;
+      float4 o;
+      o.x = adam1(pc.x, g.x, m.x, v.x, b1, b2, eps, step_size, inv_sqrt_bc2);
+      o.y = adam1(pc.y, g.y, m.y, v.y, b1, b2, eps, step_size, inv_sqrt_bc2);
+      o.z = adam1(pc.z, g.z, m.z, v.z, b1, b2, eps, step_size, inv_sqrt_bc2);
+      o.w = adam1(pc.w, g.w, m.w, v.w, b1, b2, eps, step_size, inv_sqrt_bc2);
+      stnt4(p_out + e, o);
+      stnt4(m_ + e, m);
+      stnt4(v_ + e, v);
+      stnt4(grad + e, make_float4(0.f, 0.f, 0.f, 0.f));
+      pm = pc;
+      pc = pn;
+    }
   }
   if (tv_out) {
     tv_local = pp_wave_sum(tv_local);
@@ -132,13 +156,21 @@ extern "C" int pp_grid_tv_adam_step(const float* p_in, float* p_out, float* grad
   const int q4 = channels / 4;
   const long long n = (long long)(x_end - x_begin) * size[1] * size[2] * q4;
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  int blocks = (int)((n + 255) / 256);
-  blocks = ((blocks + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_grid_tv_adam, dim3(blocks), dim3(256), 0, pp_stream(stream),
+  const int nx = x_end - x_begin;
+  const long long plane = (long long)size[1] * size[2] * q4;
+  PP_REQUIRE(plane < (1ll << 31) && n < (1ll << 40), "grid too large for 32-bit plane indexing");
+  // chunks: a multiple of 8 when possible so that chunk <-> XCD (blocks are dealt round-robin over the 8 XCDs)
+  int n_chunks = nx >= 64 ? 8 * (nx / 64 > 2 ? 2 : 1) : (nx >= 8 ? 8 : nx);
+  if (const char* ev = getenv("PP_GRID_CHUNKS")) { int c = atoi(ev); if (c > 0 && c <= nx) n_chunks = c; }   // tuning hook
+  const int chunk_len = (nx + n_chunks - 1) / n_chunks;
+  n_chunks = (nx + chunk_len - 1) / chunk_len;
+  const int tiles = (int)((plane + 255) / 256);
+  hipLaunchKernelGGL(k_grid_tv_adam, dim3(tiles * n_chunks), dim3(256), 0, pp_stream(stream),
                      reinterpret_cast<const float4*>(p_in), reinterpret_cast<float4*>(p_out),
                      reinterpret_cast<float4*>(grad), reinterpret_cast<float4*>(exp_avg),
-                     reinterpret_cast<float4*>(exp_avg_sq), size[0], size[1], size[2], q4, x_begin, x_end, tv_scale,
-                     grad_scale, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), tv_out);
+                     reinterpret_cast<float4*>(exp_avg_sq), size[0], size[1], size[2], q4, x_begin, x_end, n_chunks,
+                     chunk_len, tv_scale, grad_scale, beta1, beta2, eps, (float)((double)lr / bc1),
+                     (float)(1.0 / sqrt(bc2)), tv_out);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }

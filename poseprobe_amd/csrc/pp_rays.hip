@@ -6,17 +6,17 @@
 // ------------------------------------------------------------------------------------------------
 // forward-mode dual numbers with 6 tangents (d/d se3) - one thread per view, a few hundred ops.
 // ------------------------------------------------------------------------------------------------
+// one tangent per thread: thread (view, k) carries d/d se3[k]
 struct D6 {
   float v;
-  float d[6];
+  float d;
 };
-__device__ __forceinline__ D6 d6c(float c) { D6 r; r.v = c; for (int i = 0; i < 6; ++i) r.d[i] = 0.f; return r; }
-__device__ __forceinline__ D6 d6var(float c, int k) { D6 r = d6c(c); r.d[k] = 1.f; return r; }
-__device__ __forceinline__ D6 operator+(const D6& a, const D6& b) { D6 r; r.v = a.v + b.v; for (int i = 0; i < 6; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
-__device__ __forceinline__ D6 operator-(const D6& a, const D6& b) { D6 r; r.v = a.v - b.v; for (int i = 0; i < 6; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
-__device__ __forceinline__ D6 operator-(const D6& a) { D6 r; r.v = -a.v; for (int i = 0; i < 6; ++i) r.d[i] = -a.d[i]; return r; }
-__device__ __forceinline__ D6 operator*(const D6& a, const D6& b) { D6 r; r.v = a.v * b.v; for (int i = 0; i < 6; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
-__device__ __forceinline__ D6 operator*(const D6& a, float s) { D6 r; r.v = a.v * s; for (int i = 0; i < 6; ++i) r.d[i] = a.d[i] * s; return r; }
+__device__ __forceinline__ D6 d6c(float c) { D6 r; r.v = c; r.d = 0.f; return r; }
+__device__ __forceinline__ D6 operator+(const D6& a, const D6& b) { D6 r; r.v = a.v + b.v; r.d = a.d + b.d; return r; }
+__device__ __forceinline__ D6 operator-(const D6& a, const D6& b) { D6 r; r.v = a.v - b.v; r.d = a.d - b.d; return r; }
+__device__ __forceinline__ D6 operator-(const D6& a) { D6 r; r.v = -a.v; r.d = -a.d; return r; }
+__device__ __forceinline__ D6 operator*(const D6& a, const D6& b) { D6 r; r.v = a.v * b.v; r.d = a.d * b.v + a.v * b.d; return r; }
+__device__ __forceinline__ D6 operator*(const D6& a, float s) { D6 r; r.v = a.v * s; r.d = a.d * s; return r; }
 
 // Series of lib/camera.py:165-188 written in t = theta^2 (identical polynomial, smooth derivative at 0).
 // kind 0: sin(x)/x, 1: (1-cos x)/x^2, 2: (x-sin x)/x^3 ; 11 terms.
@@ -38,7 +38,8 @@ __device__ D6 taylor_t(const D6& t, int kind) {
 __global__ void k_pose_fwd(const float* __restrict__ se3, const float* __restrict__ w2c_init,
                            const int32_t* __restrict__ refine_mask, int n_views, float* __restrict__ w2c,
                            float* __restrict__ c2w, float* __restrict__ jac) {
-  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  int tidx = blockIdx.x * blockDim.x + threadIdx.x;
+  int v = tidx / 6, kd = tidx - (tidx / 6) * 6;       // view, tangent direction
   if (v >= n_views) return;
   const float* P0 = w2c_init + v * 12;
   D6 Rn[3][3], tn[3];
@@ -47,7 +48,10 @@ __global__ void k_pose_fwd(const float* __restrict__ se3, const float* __restric
     for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Rn[i][j] = d6c(P0[i * 4 + j]); tn[i] = d6c(P0[i * 4 + 3]); }
   } else {
     D6 w[3], u[3];
-    for (int k = 0; k < 3; ++k) { w[k] = d6var(se3[v * 6 + k], k); u[k] = d6var(se3[v * 6 + 3 + k], 3 + k); }
+    for (int k = 0; k < 3; ++k) {
+      w[k] = d6c(se3[v * 6 + k]); w[k].d = (kd == k) ? 1.f : 0.f;
+      u[k] = d6c(se3[v * 6 + 3 + k]); u[k].d = (kd == 3 + k) ? 1.f : 0.f;
+    }
     D6 t = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
     D6 A = taylor_t(t, 0), B = taylor_t(t, 1), C = taylor_t(t, 2);
     D6 z = d6c(0.f);
@@ -70,14 +74,12 @@ __global__ void k_pose_fwd(const float* __restrict__ se3, const float* __restric
   // invert: R^T, -R^T t (camera.py:76-82)
   for (int i = 0; i < 3; ++i) {
     for (int j = 0; j < 3; ++j) {
-      w2c[v * 12 + i * 4 + j] = Rn[i][j].v;
-      c2w[v * 12 + i * 4 + j] = Rn[j][i].v;
-      for (int k = 0; k < 6; ++k) jac[(v * 12 + i * 4 + j) * 6 + k] = Rn[j][i].d[k];
+      if (kd == 0) { w2c[v * 12 + i * 4 + j] = Rn[i][j].v; c2w[v * 12 + i * 4 + j] = Rn[j][i].v; }
+      jac[(v * 12 + i * 4 + j) * 6 + kd] = Rn[j][i].d;
     }
-    w2c[v * 12 + i * 4 + 3] = tn[i].v;
     D6 ti = -(Rn[0][i] * tn[0] + Rn[1][i] * tn[1] + Rn[2][i] * tn[2]);
-    c2w[v * 12 + i * 4 + 3] = ti.v;
-    for (int k = 0; k < 6; ++k) jac[(v * 12 + i * 4 + 3) * 6 + k] = ti.d[k];
+    if (kd == 0) { w2c[v * 12 + i * 4 + 3] = tn[i].v; c2w[v * 12 + i * 4 + 3] = ti.v; }
+    jac[(v * 12 + i * 4 + 3) * 6 + kd] = ti.d;
   }
 }
 
@@ -94,7 +96,7 @@ __global__ void k_pose_bwd(const float* __restrict__ jac, const float* __restric
 extern "C" int pp_pose_fwd(const float* se3, const float* w2c_init, const int32_t* refine_mask, int32_t n_views,
                            float* w2c, float* c2w, float* jac, void* stream) {
   PP_REQUIRE(se3 && w2c_init && w2c && c2w && jac && n_views > 0, "null pointer or n_views<=0");
-  hipLaunchKernelGGL(k_pose_fwd, dim3(pp_div_up(n_views, 64)), dim3(64), 0, pp_stream(stream), se3, w2c_init,
+  hipLaunchKernelGGL(k_pose_fwd, dim3(pp_div_up(n_views * 6, 64)), dim3(64), 0, pp_stream(stream), se3, w2c_init,
                      refine_mask, n_views, w2c, c2w, jac);
   PP_CHECK_LAUNCH();
   return PP_OK;

@@ -115,7 +115,7 @@ class Workspace:
         self.g_gradient, self.g_pts, self.g_view_s = e(capacity, 3, **f), e(capacity, 3, **f), e(capacity, 3, **f)
         self.g_grad_deform, self.g_corr, self.g_sdf_deform = e(capacity, 9, **f), e(capacity, **f), e(capacity, **f)
         self.g_warp_out = e(capacity, 16, **f)
-        self.scratch = e(2, capacity * 4, 128, **f)     # shared by both MLP backward chains
+        self.scratch = e(2 * capacity * 4 * 128 + 49152, **f)   # shared by both MLP backward chains (+ transposed weights)
         self.g_rays_o, self.g_rays_d, self.g_viewdirs = e(N, 3, **f), e(N, 3, **f), e(N, 3, **f)
 
 
@@ -227,7 +227,7 @@ class RenderCore:
             ws.g_alpha.add_(g_alpha_ext)
         if g_rgb_ext is not None:
             ws.g_rgb.add_(g_rgb_ext)
-        ops.rgbnet_bwd(rgbnet_p, ws.feat, ws.rgb_acts, ws.rgb, ws.g_rgb, ws.count, ws.cap, ws.scratch.view(-1)[:2 * ws.cap * 128],
+        ops.rgbnet_bwd(rgbnet_p, ws.feat, ws.rgb_acts, ws.rgb, ws.g_rgb, ws.count, ws.cap, ws.scratch[-(2 * ws.cap * 128 + 49152):],
                        rgbnet_grad, ws.g_feat)
         ops.color_feat_bwd(sc, k0_cl, ws.pts, ws.viewdirs, ws.ray_id, ws.gradient, pe_w, ws.count, ws.cap, ws.g_feat,
                            k0_grad_cl, ws.g_pts, ws.g_gradient, ws.g_view_s)
