@@ -30,6 +30,18 @@ HBM_PEAK_GBS = 8000.0       # MI355X spec (MI355X_MICROARCH.md: 8 TB/s spec, ~6.
 GRID_BYTES_PER_VOXEL = 384  # fused pass, C=12 fp32: read p,g,m,v (192) + write p',m,v,g=0 (192)
 
 
+def pmc_traffic(grid, voxels):
+    """HBM bytes per launch of k_grid_tv_adam from the committed rocprofv3 PMC passes (profiles/r01_grid_traffic.json:
+    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KB -> bytes), only when it was collected for this grid size."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'r01_grid_traffic.json')))
+        if int(rec['grid']) == int(grid) and int(rec['voxels_per_launch']) == int(voxels):
+            return float(rec['hbm_bytes_per_launch'])
+    except Exception:
+        pass
+    return None
+
+
 def init_engine_params(eng, cfg, seed):
     """Random-init parameters of the reference's architecture (cube-init SDF, k0~N(0,.1), warp last layer N(0,1e-2))."""
     from poseprobe_amd.params_init import reference_like_params
@@ -83,9 +95,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dctx = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('PP_FORCE_DIST') == '1'     # PP_FORCE_DIST: rehearse the RCCL path on 1 rank
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         from poseprobe_amd.dist import DistContext
         dctx = DistContext()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
@@ -110,7 +125,7 @@ def main():
     jit_all = torch.tensor(np.stack(jit_all), dtype=torch.float32, device=dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -138,7 +153,7 @@ def main():
         eng.train_step(idx_all[s], jit_all[s], gs + s)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -160,14 +175,14 @@ def main():
                        'parallelism': f'ray-sharded dp{world}, ZeRO-1 grid optimiser' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'kernel': 'k_grid_tv_adam (fused TV-grad + Adam + zero-grad over k0)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'ms_per_launch': grid_ms, 'algorithmic_bytes_per_launch': grid_bytes},
+                         'traffic': pmc_traffic(G, (xe - xb) * Y * Z), 'ms_per_launch': grid_ms, 'algorithmic_bytes_per_launch': grid_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(G, H, W, V, N, views, args.cpu_budget)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -76,16 +76,52 @@ class DistContext:
             t.copy_(self._bucket[o:o + t.numel()].view_as(t))
             o += t.numel()
 
-    # ---- hooks used by engine.TrainEngine.train_step ------------------------------------------------------------
-    def reduce_gradients(self, eng):
-        if self.shardable(eng.k0_grad.shape[0]):
-            eng.x_slab = self.reduce_scatter_grid(eng.k0_grad)
+    # ---- hooks used by engine.TrainEngine (overlap of the two big collectives with compute) -------------------
+    def start_grid_reduce(self, eng):
+        """Called right after the k0 scatter kernel: the dense reduce-scatter (async, RCCL stream) overlaps the
+        geometry / warp-MLP backward, which does not touch the grid gradient."""
+        X = eng.k0_grad.shape[0]
+        if self.shardable(X) and self.backend != 'gloo':
+            xb, xe = slab_bounds(X, self.world, self.rank)
+            self._grid_work = dist.reduce_scatter_tensor(eng.k0_grad[xb:xe], eng.k0_grad, op=dist.ReduceOp.SUM,
+                                                         group=self.group, async_op=True)
         else:
-            dist.all_reduce(eng.k0_grad, group=self.group)
-            eng.x_slab = (0, eng.k0_grad.shape[0])
+            self._grid_work = dist.all_reduce(eng.k0_grad, group=self.group, async_op=True)
+
+    def reduce_gradients(self, eng):
+        X = eng.k0_grad.shape[0]
+        work = getattr(self, '_grid_work', None)
+        if work is None:
+            self.start_grid_reduce(eng)
+            work = self._grid_work
+        work.wait()
+        self._grid_work = None
+        if self.shardable(X):
+            xb, xe = slab_bounds(X, self.world, self.rank)
+            if xb > 0:
+                eng.k0_grad[:xb].zero_()
+            if xe < X:
+                eng.k0_grad[xe:].zero_()
+            eng.x_slab = (xb, xe)
+        else:
+            eng.x_slab = (0, X)
         self.all_reduce_small([eng.flat.grad, eng.se3_grad])
         eng.grad_scale = 1.0 / self.world
 
     def gather_parameters(self, eng):
-        if self.shardable(eng.k0_grad.shape[0]):
-            self.all_gather_grid(eng.k0_cl)
+        """Async all-gather of the updated slabs; the next step waits for it only right before its first k0 lookup."""
+        X = eng.k0_grad.shape[0]
+        self._param_work = None
+        if self.shardable(X):
+            if self.backend == 'gloo':
+                self.all_gather_grid(eng.k0_cl)
+            else:
+                xb, xe = slab_bounds(X, self.world, self.rank)
+                self._param_work = dist.all_gather_into_tensor(eng.k0_cl, eng.k0_cl[xb:xe], group=self.group,
+                                                               async_op=True)
+
+    def wait_parameters(self, eng):
+        work = getattr(self, '_param_work', None)
+        if work is not None:
+            work.wait()
+            self._param_work = None

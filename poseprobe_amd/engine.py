@@ -203,11 +203,13 @@ class RenderCore:
         ops.sample_dense(self.cfg.pp, ws.rays_o, ws.rays_d, jitter, ws.sample_cap, ws.t_min, ws.t_max, ws.ray_start, ws.count,
                          ws.pts, ws.ray_id, ws.step_k, ws.step)
 
-    def forward(self, ws, k0_cl, sdf, sdf_ab, rgbnet_p, warp_p, inv_s, pe_w, step_w=None):
+    def forward(self, ws, k0_cl, sdf, sdf_ab, rgbnet_p, warp_p, inv_s, pe_w, step_w=None, before_k0_use=None):
         cfg, sc = self.cfg, self.cfg.pp
         ops.warp_fwd(warp_p, ws.pts, ws.count, ws.cap, cfg.out_range, ws.warp_acts, ws.warp_out)
         ops.geometry_fwd(sc, sdf, sdf_ab, ws.pts, ws.warp_out, ws.viewdirs, ws.ray_id, ws.count, ws.cap, inv_s,
                          ws.alpha, ws.gradient, ws.sdf_final, ws.sdf_deform, ws.grad_deform)
+        if before_k0_use is not None:
+            before_k0_use()             # multi-GPU: the all-gather of the updated grid overlaps everything above
         ops.color_feat_fwd(sc, k0_cl, ws.pts, ws.viewdirs, ws.ray_id, ws.gradient, pe_w, ws.count, ws.cap, ws.feat)
         ops.rgbnet_fwd(rgbnet_p, ws.feat, ws.count, ws.cap, ws.rgb_acts, ws.rgb)
         ops.march_fwd(ws.alpha, ws.rgb, ws.step if step_w is None else step_w, None, ws.ray_start, ws.N, cfg.bg,
@@ -217,7 +219,7 @@ class RenderCore:
     # -- backward ------------------------------------------------------------------------------------------
     def backward(self, ws, k0_cl, sdf, sdf_ab, rgbnet_p, warp_p, inv_s, pe_w, k0_grad_cl, sdf_ab_grad, rgbnet_grad,
                  warp_grad, g_depth=None, g_weights=None, g_gradient_ext=None, g_sdf_deform=None, g_grad_deform=None,
-                 g_correction=None, g_alpha_ext=None, g_rgb_ext=None):
+                 g_correction=None, g_alpha_ext=None, g_rgb_ext=None, after_k0_grad=None):
         """Consumes ws.g_rgbm / ws.g_last / ws.g_cw (+ optional per-sample upstream grads), accumulates parameter
         grads (atomic +=) and leaves d/d ray_pts in ws.g_pts and the per-sample viewdir grads in ws.g_view_s."""
         cfg, sc = self.cfg, self.cfg.pp
@@ -231,6 +233,8 @@ class RenderCore:
                        rgbnet_grad, ws.g_feat)
         ops.color_feat_bwd(sc, k0_cl, ws.pts, ws.viewdirs, ws.ray_id, ws.gradient, pe_w, ws.count, ws.cap, ws.g_feat,
                            k0_grad_cl, ws.g_pts, ws.g_gradient, ws.g_view_s)
+        if after_k0_grad is not None:
+            after_k0_grad()             # multi-GPU: the grid reduce-scatter overlaps the rest of the backward
         if g_gradient_ext is not None:
             g_gradient_ext(ws)      # callable adding loss terms into ws.g_gradient etc. (fused step) ...
         ops.geometry_bwd(sc, sdf, sdf_ab, ws.pts, ws.warp_out, ws.viewdirs, ws.ray_id, ws.count, ws.cap, inv_s,
@@ -334,7 +338,8 @@ class TrainEngine:
         s_val = cfg.s_val(global_step)
         inv_s = float(np.float32(1.0) / np.float32(s_val))
         P = self.flat
-        self.core.forward(ws, self.k0_cl, self.sdf, P.view('sdf_ab'), P.view('rgbnet'), P.view('warp'), inv_s, self.pe_w)
+        self.core.forward(ws, self.k0_cl, self.sdf, P.view('sdf_ab'), P.view('rgbnet'), P.view('warp'), inv_s, self.pe_w,
+                          before_k0_use=None if self.dist is None else (lambda: self.dist.wait_parameters(self)))
         ws.loss_out.zero_()
         w_dyn = dynamic_weight(1e-1, 1e-3, global_step, cfg.N_iters)
         ls = self.loss_scale
@@ -348,7 +353,8 @@ class TrainEngine:
         self.core.backward(ws, self.k0_cl, self.sdf, P.view('sdf_ab'), P.view('rgbnet'), P.view('warp'), inv_s, self.pe_w,
                            self.k0_grad, P.view('sdf_ab', 'grad'), P.view('rgbnet', 'grad'), P.view('warp', 'grad'),
                            g_gradient_ext=add_sample_losses, g_sdf_deform=ws.g_sdf_deform,
-                           g_grad_deform=ws.g_grad_deform, g_correction=ws.g_corr)
+                           g_grad_deform=ws.g_grad_deform, g_correction=ws.g_corr,
+                           after_k0_grad=None if self.dist is None else (lambda: self.dist.start_grid_reduce(self)))
         ops.raygen_select_bwd(sc, ray_idx, self.c2w, self.intr, self.H, self.W, cfg.inverse_y, ws.rays_o, ws.rays_d,
                               ws.t_min, ws.ray_start, ws.g_pts, ws.step, ws.g_view_s, None, None, None, None, None, None,
                               None, self.c2w_grad)
