@@ -231,6 +231,15 @@ int pp_grid_sample_bwd(const pp_scene* sc, const float* grid_cl, int32_t channel
 int pp_grid_tv_grad(const float* p, int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, float scale,
                     const float* g_scalar, float* grad, void* stream);
 
+/* Surface-point query (Voxurf.query_sdf_point_wocuda / _wodeform, voxurf_coarse.py:766-795, :809-837): first sign
+ * change of the per-ray SDF samples and the linear zero crossing.  Compact mode: sdf[M] + ray_start[N+1] + step_k[M]
+ * (out-of-bbox slots take the reference's default 1); dense mode (ray_start = step_k = NULL): sdf[N,S].
+ * Outputs: pts[N,3] = o + d*(t_min + z0/|d|), mask[N] (uint8), optional sdf_dense[N,S], zval[N]. */
+int pp_sdf_first_crossing(const float* sdf, const int32_t* ray_start, const int32_t* step_k, int32_t n_rays,
+                          int32_t n_samples, float dist, const float* t_min, const float* rays_o,
+                          const float* rays_d, float* sdf_dense, float* pts, uint8_t* mask, float* zval,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,8 @@ def parse_header(path=HEADER):
                 ct = ctypes.POINTER(pp_scene)
             elif '*' in a:
                 ct = ctypes.c_void_p
+            elif 'uint8_t' in a and '*' not in a:
+                ct = ctypes.c_uint8
             elif 'int32_t' in a or a.startswith('int '):
                 ct = ctypes.c_int32
             elif 'float' in a:

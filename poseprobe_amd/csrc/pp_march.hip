@@ -172,3 +172,68 @@ extern "C" int pp_march_bwd(const float* alpha, const float* rgb, const float* s
   PP_CHECK_LAUNCH();
   return PP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Surface-point query: first sign change of the SDF along a ray + linear zero crossing
+// (Voxurf.query_sdf_point_wocuda / _wodeform, lib/voxurf_coarse.py:766-795, :809-837).  One wavefront per ray.
+// Compact mode (ray_start != NULL): sdf[M] holds the in-bbox samples, the dense row is rebuilt with the reference's
+// default value 1 for out-of-bbox slots (:752).  Dense mode: sdf is already [N,S].
+// ------------------------------------------------------------------------------------------------------------------
+#define PP_MAX_S 1024
+__global__ __launch_bounds__(256) void k_first_crossing(const float* __restrict__ sdf, const int32_t* __restrict__ ray_start,
+                                                        const int32_t* __restrict__ step_k, int n_rays, int S, float dist,
+                                                        const float* __restrict__ t_min, const float* __restrict__ rays_o,
+                                                        const float* __restrict__ rays_d, float* __restrict__ sdf_dense,
+                                                        float* __restrict__ pts, uint8_t* __restrict__ mask,
+                                                        float* __restrict__ zval) {
+  __shared__ float rows[4][PP_MAX_S];
+  int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int r = blockIdx.x * 4 + wid;
+  if (r >= n_rays) return;
+  float* row = rows[wid];
+  if (ray_start) {
+    for (int k = lane; k < S; k += 64) row[k] = 1.f;
+    __builtin_amdgcn_wave_barrier();
+    for (int i = ray_start[r] + lane; i < ray_start[r + 1]; i += 64) row[step_k[i]] = sdf[i];
+  } else {
+    for (int k = lane; k < S; k += 64) row[k] = sdf[(size_t)r * S + k];
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (sdf_dense) for (int k = lane; k < S; k += 64) sdf_dense[(size_t)r * S + k] = row[k];
+  int prev = 0;                                        // argmax of an all-zero row is 0 (voxurf_coarse.py:771)
+  for (int k0 = 0; k0 < S - 1; k0 += 64) {
+    int k = k0 + lane;
+    bool hit = (k < S - 1) && (row[k] * row[k + 1] <= 0.f);
+    unsigned long long bal = __ballot(hit);
+    if (bal) { prev = k0 + __ffsll((long long)bal) - 1; break; }
+  }
+  if (lane == 0) {
+    float s1 = row[prev], s2 = row[prev + 1];
+    float z1 = (float)prev * dist + dist * 0.5f, z2 = (float)(prev + 1) * dist + dist * 0.5f;
+    float z0 = (s1 * z2 - s2 * z1) / (s1 - s2 + 1e-10f);
+    if (z0 < z1) z0 = 0.f;
+    if (z0 > z2) z0 = 0.f;
+    bool ok = (z0 > 1e-10f) && (s1 * s2 < 0.f);
+    float dx = rays_d[r * 3], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
+    float nrm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    float interpx = t_min[r] + z0 / nrm;
+    pts[r * 3] = rays_o[r * 3] + dx * interpx;
+    pts[r * 3 + 1] = rays_o[r * 3 + 1] + dy * interpx;
+    pts[r * 3 + 2] = rays_o[r * 3 + 2] + dz * interpx;
+    mask[r] = ok ? 1 : 0;
+    if (zval) zval[r] = z0;
+  }
+}
+
+extern "C" int pp_sdf_first_crossing(const float* sdf, const int32_t* ray_start, const int32_t* step_k, int32_t n_rays,
+                                     int32_t n_samples, float dist, const float* t_min, const float* rays_o,
+                                     const float* rays_d, float* sdf_dense, float* pts, uint8_t* mask, float* zval,
+                                     void* stream) {
+  PP_REQUIRE(sdf && t_min && rays_o && rays_d && pts && mask, "null pointer");
+  PP_REQUIRE((ray_start == nullptr) == (step_k == nullptr), "ray_start and step_k go together");
+  PP_REQUIRE(n_rays > 0 && n_samples >= 2 && n_samples <= PP_MAX_S, "need n_rays>0 and 2<=n_samples<=1024");
+  hipLaunchKernelGGL(k_first_crossing, dim3(pp_div_up(n_rays, 4)), dim3(256), 0, pp_stream(stream), sdf, ray_start, step_k,
+                     n_rays, n_samples, dist, t_min, rays_o, rays_d, sdf_dense, pts, mask, zval);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}

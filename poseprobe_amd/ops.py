@@ -219,3 +219,8 @@ def grid_sample_bwd(sc, grid_cl, channels, pts, border, out_grad, grid_grad_cl, 
 def grid_tv_grad(p, size, channels, scale, g_scalar, grad):
     _lib.call('pp_grid_tv_grad', _f(p), int(size[0]), int(size[1]), int(size[2]), channels, float(scale), _f(g_scalar),
               _f(grad), _stream())
+
+
+def sdf_first_crossing(sdf, ray_start, step_k, n_rays, n_samples, dist, t_min, rays_o, rays_d, sdf_dense, pts, mask, zval):
+    _lib.call('pp_sdf_first_crossing', _f(sdf), _i(ray_start), _i(step_k), n_rays, n_samples, float(dist), _f(t_min),
+              _f(rays_o), _f(rays_d), _f(sdf_dense), _f(pts), _ptr(mask, torch.uint8), _f(zval), _stream())

@@ -138,12 +138,12 @@ class _VoxurfRender(torch.autograd.Function):
         depth = ws.t_min / rays_d.detach().norm(dim=-1) + ws.depth_acc
         outs = (ws.rgb_marched, ws.alphainv_last, ws.cum_weights.unsqueeze(-1), ws.weights[:M], ws.alpha[:M], ws.rgb[:M],
                 depth, ws.gradient[:M], ws.sdf_deform[:M], ws.grad_deform[:M].reshape(M, 3, 3),
-                ws.warp_out[:M, 3:4])
+                ws.warp_out[:M, 3:4], ws.depth_acc)
         return tuple(o.clone() for o in outs)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_rgbm, g_last, g_cw, g_w, g_alpha, g_rgb, g_depth, g_grad, g_sdfd, g_gdef, g_corr):
+    def backward(ctx, g_rgbm, g_last, g_cw, g_w, g_alpha, g_rgb, g_depth, g_grad, g_sdfd, g_gdef, g_corr, g_nstep):
         model, ws, flat = ctx.model, ctx.ws, ctx.flat
         core, M, cap = model._core, ws.M, ws.cap
         ws.alloc_backward()
@@ -168,7 +168,8 @@ class _VoxurfRender(torch.autograd.Function):
         k0_grad = torch.zeros_like(ctx.k0, memory_format=torch.channels_last_3d)
         core.backward(ws, channels_last_view(ctx.k0), ctx.sdf_g, flat.view('sdf_ab'), flat.view('rgbnet'), flat.view('warp'),
                       ctx.inv_s, ctx.pe_w, channels_last_view(k0_grad), flat.view('sdf_ab', 'grad'),
-                      flat.view('rgbnet', 'grad'), flat.view('warp', 'grad'), g_depth=g_depth, g_weights=padded(g_w),
+                      flat.view('rgbnet', 'grad'), flat.view('warp', 'grad'),
+                      g_depth=(g_depth + g_nstep.contiguous().float()), g_weights=padded(g_w),
                       g_gradient_ext=add_gradient, g_sdf_deform=padded(g_sdfd), g_grad_deform=padded(g_gdef, 9),
                       g_correction=padded(g_corr), g_alpha_ext=padded(g_alpha), g_rgb_ext=padded(g_rgb, 3))
         go, gd, gv = (torch.empty_like(ws.rays_o) for _ in range(3))
@@ -414,6 +415,89 @@ class Voxurf(torch.nn.Module):
         pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
         return pts, ~keep, step, b['t_min'], b['t_max']
 
+
+    # ---- surface-point queries (voxurf_coarse.py:734-920) -------------------------------------------------------
+    @torch.no_grad()
+    def _query_crossing(self, rays_o, rays_d, global_step, use_deform, mapped, render_kwargs):
+        self._check_inputs(rays_o, rays_d)
+        core = self._scene(dict(bg=0, **{k: render_kwargs[k] for k in ('near', 'far', 'stepsize')}))
+        cfg = core.cfg
+        ro, rd = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
+        N, S, dev = ro.shape[0], cfg.n_samples, ro.device
+        is_train = global_step is not None
+        jitter = None
+        if is_train:
+            jitter = render_kwargs.get('jitter')
+            jitter = torch.rand(N, device=dev) if jitter is None else jitter.to(dev).float().contiguous()
+        dist = float(np.float32(cfg.stepsize) * np.float32(cfg.voxel_size))
+        pts_out = torch.empty(N, 3, device=dev)
+        mask = torch.empty(N, device=dev, dtype=torch.uint8)
+        sdf_d = torch.empty(N, S, device=dev)
+        if mapped:
+            sb = self._sample_dense(core, ro, rd, jitter)
+            M = sb['M']
+            cap = max(M, 1)
+            vd = rd / rd.norm(dim=-1, keepdim=True)
+            warp_out = torch.zeros(cap, 16, device=dev)
+            flat = FlatParams(dev)
+            mlp = self._mlp_tensors()
+            flat.load_reference(self.sdf_alpha, self.sdf_beta, [(mlp[2 * k], mlp[2 * k + 1]) for k in range(4)],
+                                [(mlp[8 + 2 * k], mlp[8 + 2 * k + 1]) for k in range(5)])
+            if use_deform and M > 0:
+                acts = torch.empty(4, cap * 4, 128, device=dev)
+                ops.warp_fwd(flat.view('warp'), sb['pts'], sb['count'], cap, cfg.out_range, acts, warp_out)
+            alpha, grad, sdf_final = torch.empty(cap, device=dev), torch.empty(cap, 3, device=dev), torch.zeros(cap, device=dev)
+            if M > 0:
+                ops.geometry_fwd(cfg.pp, self.sdf.grid[0, 0].contiguous(), flat.view('sdf_ab'), sb['pts'], warp_out,
+                                 vd.contiguous(), sb['ray_id'], sb['count'], cap, 1.0, alpha, grad, sdf_final, None, None)
+            ops.sdf_first_crossing(sdf_final, sb['ray_start'], sb['step_k'], N, S, dist, sb['t_min'], ro, rd, sdf_d,
+                                   pts_out, mask, None)
+        else:
+            # _wodeform: RAW template, every dense slot looked up with border padding (voxurf_coarse.py:805-809)
+            pts_all, _, _, t_min, _ = self.sample_ray_ori(ro, rd, render_kwargs['near'], render_kwargs['far'],
+                                                          render_kwargs['stepsize'], is_train=is_train, jitter=jitter)
+            dense = torch.empty(N * S, 1, device=dev)
+            ops.grid_sample_fwd(cfg.pp, self.sdf.grid[0, 0].contiguous(), 1, pts_all.reshape(-1, 3).contiguous(), 1, dense)
+            ops.sdf_first_crossing(dense.reshape(N, S).contiguous(), None, None, N, S, dist, t_min, ro, rd, sdf_d, pts_out,
+                                   mask, None)
+        return pts_out, mask.bool(), sdf_d
+
+    def _query_finish(self, rays_o, rays_d, pts, mask, sdf_d, keep_dim, return_depth, t_min_fn=None):
+        if keep_dim:
+            return pts, mask, sdf_d
+        if return_depth:
+            depth = ((pts - rays_o) * rays_d).sum(-1) / (rays_d * rays_d).sum(-1) / 1.0
+            # interpx = z0 + t_min/|d| in the reference (:792); with unit rays_d this equals the distance along the ray
+            return pts[mask], (depth * rays_d.norm(dim=-1))[mask]
+        return pts[mask]
+
+    def query_sdf_point_wocuda(self, rays_o, rays_d, global_step=None, keep_dim=False, return_depth=False,
+                               use_deform=False, **render_kwargs):
+        """voxurf_coarse.py:734-795 (forward only: the HIP path does not differentiate through the zero crossing)."""
+        pts, mask, sdf_d = self._query_crossing(rays_o, rays_d, global_step, use_deform, True, render_kwargs)
+        return self._query_finish(rays_o, rays_d, pts, mask, sdf_d, keep_dim, return_depth)
+
+    def query_sdf_point_wocuda_wodeform(self, rays_o, rays_d, global_step=None, keep_dim=False, return_depth=False,
+                                        **render_kwargs):
+        """voxurf_coarse.py:797-837"""
+        pts, mask, sdf_d = self._query_crossing(rays_o, rays_d, global_step, False, False, render_kwargs)
+        return self._query_finish(rays_o, rays_d, pts, mask, sdf_d, keep_dim, return_depth)
+
+    def query_sdf_point_wocuda_render(self, rays_o, rays_d, global_step=None, keep_dim=False, return_depth=False,
+                                      use_deform=True, **render_kwargs):
+        """voxurf_coarse.py:839-920: expected depth from the rendering weights; differentiable (pose, warp, grid) because
+        it runs through the same autograd node as forward()."""
+        viewdirs = rays_d / rays_d.norm(dim=-1, keepdim=True)
+        out = self.forward(rays_o, rays_d, viewdirs, use_deform=use_deform, global_step=global_step, **render_kwargs)
+        nrm = rays_d.norm(dim=-1)
+        n_step = out['_n_step']                                            # = sum_i w_i step_i (differentiable)
+        depth = out['_t_min'][..., None] + n_step[..., None] / nrm[..., None]
+        mask = n_step > 0.
+        if keep_dim:
+            return rays_o + rays_d * depth, mask, depth
+        pts = rays_o[mask] + rays_d[mask] * depth[mask]
+        return (pts, depth[mask]) if return_depth else pts
+
     # ---- forward ----------------------------------------------------------------------------------------------
     def forward(self, rays_o, rays_d, viewdirs, use_deform=True, global_step=None, **render_kwargs):
         """voxurf_coarse.py:922-1092.  Extension: render_kwargs['jitter'] ([N] in [0,1)) overrides the internally drawn
@@ -447,7 +531,7 @@ class Voxurf(torch.nn.Module):
         outs = _VoxurfRender.apply(self, ws, inv_s, pe_w, ro, rd, vd, self.k0.grid, self.sdf_alpha, self.sdf_beta,
                                    *self._mlp_tensors())
         (rgb_marched, alphainv_last, cum_weights, weights, alpha, rgb, depth, gradient, sdf_deform, grad_deform,
-         correction) = outs
+         correction, n_step) = outs
         normal_marched = None
         if render_kwargs.get('render_grad', False):
             normal = gradient.detach() / (gradient.detach().norm(2, -1, keepdim=True) + 1e-6)
@@ -459,6 +543,7 @@ class Voxurf(torch.nn.Module):
             'mask': sb['keep'].bool(), 'mask_outbbox': torch.zeros(M, dtype=torch.bool, device=ro.device),
             'gradient': gradient, 's_val': s_val, 'k0_tv': self.k0_total_variation(), 'sdf_deform': sdf_deform,
             'grad_deform': grad_deform, 'sdf_correct': correction,
+            '_t_min': ws.t_min, '_n_step': n_step,   # extras (not in the reference dict) for query_sdf_point_wocuda_render
         }
 
     @torch.no_grad()

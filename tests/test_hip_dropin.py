@@ -137,3 +137,32 @@ def test_dense_grid_lookup_matches_torch_grid_sample():
     assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6, name='value')
     assert_close(g.grid.grad.cpu(), ref_grid.grad, rtol=1e-4, atol=1e-6, name='grid grad')
     assert_close(pts.grad.cpu(), p.grad, rtol=1e-4, atol=1e-5, name='pts grad')
+
+
+def test_surface_point_queries_match_reference():
+    """query_sdf_point_wocuda / _wodeform / _render (lib/voxurf_coarse.py:734-920) against the reference's outputs."""
+    d = load('query_g24.npz')
+    m = make_model(d)
+    ro, rd = torch.tensor(d['rays_o']).cuda(), torch.tensor(d['rays_d']).cuda()
+    rk = dict(near=0.24, far=4.8, bg=0, stepsize=1.5, inverse_y=True, flip_x=False, flip_y=False)
+    c = lambda t: t.detach().cpu().numpy()
+    jit = torch.tensor(d['jitter'])
+    for use_deform in (True, False):
+        for gs, tag in ((None, 'eval'), (50, 'train')):
+            key = f'q_{"deform" if use_deform else "plain"}_{tag}'
+            pts, mask, sdf_d = m.query_sdf_point_wocuda(ro, rd, global_step=gs, keep_dim=True, use_deform=use_deform,
+                                                        jitter=jit, **rk)
+            assert_close(c(sdf_d), d[key + '_sdf'], rtol=1e-4, atol=1e-5, name=key + ' sdf')
+            assert np.array_equal(c(mask), d[key + '_mask']), key
+            assert_close(c(pts)[d[key + '_mask']], d[key + '_pts'][d[key + '_mask']], rtol=1e-4, atol=2e-5, name=key + ' pts')
+    pts, mask, sdf_d = m.query_sdf_point_wocuda_wodeform(ro, rd, global_step=None, keep_dim=True, **rk)
+    assert_close(c(sdf_d), d['q_wodeform_sdf'], rtol=1e-4, atol=1e-5, name='wodeform sdf')
+    assert np.array_equal(c(mask), d['q_wodeform_mask'])
+    assert_close(c(pts)[d['q_wodeform_mask']], d['q_wodeform_pts'][d['q_wodeform_mask']], rtol=1e-4, atol=2e-5, name='wodeform pts')
+    ro_g = ro.clone().requires_grad_(True)
+    pts, mask, depth = m.query_sdf_point_wocuda_render(ro_g, rd, global_step=50, keep_dim=True, use_deform=True, jitter=jit, **rk)
+    assert np.array_equal(c(mask), d['q_render_mask'])
+    assert_close(c(depth), d['q_render_depth'], rtol=1e-4, atol=1e-5, name='render depth')
+    assert_close(c(pts), d['q_render_pts'], rtol=1e-4, atol=2e-5, name='render pts')
+    pts.sum().backward()                 # differentiable w.r.t. the rays (-> pose)
+    assert torch.isfinite(ro_g.grad).all() and float(ro_g.grad.abs().sum()) > 0
