@@ -240,6 +240,30 @@ int pp_sdf_first_crossing(const float* sdf, const int32_t* ray_start, const int3
                           const float* rays_d, float* sdf_dense, float* pts, uint8_t* mask, float* zval,
                           void* stream);
 
+/* ---------------------------------------------------------------- DVGO-surface operators of the reference's
+ * extensions that the live loop never calls (SURVEY.md 2a "dead"), kept for API completeness:
+ * raw2alpha{,_nonuni}{,_backward} (render_utils_kernel.cu:431-574; interval_v != NULL selects the per-point form),
+ * maskcache_lookup (:374-424; world[X,Y,Z] uint8), sample_ndc_pts_on_rays (:245-293), sample_bg_pts_on_rays (:301-360),
+ * adam_upd / masked_adam_upd / adam_upd_with_perlr (adam_upd_kernel.cu:8-133; mode 0/1/2),
+ * total_variation_add_grad{,_new} (total_variation_kernel.cu:13-134; channels-last grids, mask_cl != NULL selects
+ * the masked form), cumdist_thres (ub360_utils_kernel.cu:12-48). */
+int pp_raw2alpha_fwd(const float* density, float shift, float interval, const float* interval_v, int32_t n,
+                     float* exp_d, float* alpha, void* stream);
+int pp_raw2alpha_bwd(const float* exp_d, const float* grad_back, float interval, const float* interval_v, int32_t n,
+                     float* grad, void* stream);
+int pp_maskcache_lookup(const uint8_t* world, const float* xyz, int32_t size_x, int32_t size_y, int32_t size_z,
+                        float scale_x, float scale_y, float scale_z, float shift_x, float shift_y, float shift_z,
+                        int32_t n, uint8_t* out, void* stream);
+int pp_sample_ndc(const pp_scene* sc, const float* rays_o, const float* rays_d, int32_t n_rays, int32_t n_samples,
+                  float* pts, uint8_t* mask_outbbox, void* stream);
+int pp_sample_bg(const float* rays_o, const float* rays_d, const float* t_max, float bg_preserve, int32_t n_rays,
+                 int32_t n_samples, float* pts, void* stream);
+int pp_adam_upd(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* perlr, int32_t n,
+                int32_t step, float beta1, float beta2, float lr, float eps, int32_t mode, void* stream);
+int pp_tv_add_grad(const float* param_cl, float* grad_cl, const float* mask_cl, int32_t size_x, int32_t size_y,
+                   int32_t size_z, int32_t channels, float wx, float wy, float wz, int32_t dense_mode, void* stream);
+int pp_cumdist_thres(const float* dist, float thres, int32_t n_rays, int32_t n_pts, uint8_t* mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
