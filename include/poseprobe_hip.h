@@ -264,6 +264,34 @@ int pp_tv_add_grad(const float* param_cl, float* grad_cl, const float* mask_cl, 
                    int32_t size_z, int32_t channels, float wx, float wy, float wz, int32_t dense_mode, void* stream);
 int pp_cumdist_thres(const float* dist, float thres, int32_t n_rays, int32_t n_pts, uint8_t* mask, void* stream);
 
+/* ---------------------------------------------------------------- DirectVoxGO twin (lib/dvgo_ori.py:289-379).
+ * Generic feature builder: [k0 (channels k0_skip..C) | xyz PE | view PE | optional normal], row stride ld (multiple of
+ * 32), un-weighted encodings when pe_w == NULL, sel[M] (uint8, optional) = weights > fast_color_thres mask, optional
+ * k0_raw[M,C] copy of the interpolated features (k0_diffuse for rgbnet_direct=False). */
+int pp_feat_generic_fwd(const pp_scene* sc, const float* k0_cl, const float* pts, const float* viewdirs,
+                        const int32_t* ray_id, const float* gradient, const float* pe_w, const uint8_t* sel,
+                        int32_t k0_skip, int32_t ld, const int32_t* count, int32_t capacity, float* feat,
+                        float* k0_raw, void* stream);
+int pp_feat_generic_bwd_k0(const pp_scene* sc, const float* pts, const uint8_t* sel, int32_t k0_skip, int32_t ld,
+                           const int32_t* count, int32_t capacity, const float* feat_grad,
+                           const float* k0_raw_grad, float* k0_grad_cl, void* stream);
+/* Generic ReLU MLP in_ld -> 128 x n_gemm -> 3 + sigmoid on the matrix cores.  Parameter block:
+ * W0[128*in_ld] b0[128] | (W[128*128] b[128]) x (n_gemm-1) | Wout[3*128] bout[3].  logit_add[M,ld] (optional) is
+ * added to the logits before the sigmoid (k0_diffuse, dvgo_ori.py:359).  acts[n_gemm][cap][128];
+ * scratch [2][cap][128] + 16384. */
+int pp_mlp_fwd(const float* params, const float* feat, int32_t in_ld, int32_t n_gemm, const int32_t* count,
+               int32_t capacity, const float* logit_add, int32_t logit_add_ld, float* acts, float* out,
+               void* stream);
+int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld, int32_t n_gemm, const float* acts,
+               const float* out, const float* out_grad, const int32_t* count, int32_t capacity, float* scratch,
+               float* params_grad, float* feat_grad, float* logit_add_grad, int32_t logit_add_ld, void* stream);
+/* cumprod_exclusive(clamp_min(1-alpha,1e-10)) compositing without early stop (dvgo_ori.py:478-489): weights[M], T[M],
+ * alphainv_last[N], rgb_acc[N,3] = sum w*rgb (un-clamped, bg not added), cum_weights[N], depth_acc[N] = sum w*step_w.
+ * The backward is pp_march_bwd. */
+int pp_march_dvgo_fwd(const float* alpha, const float* rgb, const float* step_w, const int32_t* ray_start,
+                      int32_t n_rays, float* weights, float* T, float* alphainv_last, int32_t* i_end,
+                      float* rgb_acc, float* cum_weights, float* depth_acc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

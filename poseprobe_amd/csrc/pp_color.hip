@@ -219,6 +219,125 @@ __global__ __launch_bounds__(256) void k_k0_scatter(SceneDev sc, const float* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Generic feature builder (DirectVoxGO twin, lib/dvgo_ori.py:336-352): [k0 (C - k0_skip channels) | xyz, sin, cos |
+// view, sin, cos | optional normal] with runtime widths, un-weighted encodings when pe_w == NULL, row stride `ld`.
+// `sel[M]` (uint8, optional) marks the samples that take part (weights > fast_color_thres); others get zero rows.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_feat_generic_fwd(SceneDev sc, const float* __restrict__ k0,
+                                                          const float* __restrict__ pts, const float* __restrict__ viewdirs,
+                                                          const int32_t* __restrict__ ray_id,
+                                                          const float* __restrict__ gradient, const float* __restrict__ pe_w,
+                                                          const uint8_t* __restrict__ sel, int k0_skip, int ld,
+                                                          const int32_t* __restrict__ count, int capacity,
+                                                          float* __restrict__ feat, float* __restrict__ k0_raw) {
+  int m = blockIdx.x * blockDim.x + threadIdx.x;
+  int M = min(count[0], capacity);
+  if (m >= M) return;
+  float* f = feat + (size_t)m * ld;
+  for (int i = 0; i < ld; ++i) f[i] = 0.f;
+  if (k0_raw) for (int c = 0; c < sc.C; ++c) k0_raw[(size_t)m * sc.C + c] = 0.f;
+  if (sel && !sel[m]) return;
+  float p[3] = {pts[m * 3], pts[m * 3 + 1], pts[m * 3 + 2]};
+  K0Tri t;
+  k0_setup(sc, p, t);
+  const int C = sc.C, Lp = sc.Lp, Lv = sc.Lv;
+  for (int c = 0; c < 8; ++c) {
+    size_t off; float w;
+    if (k0_corner(sc, t, c, off, w))
+      for (int ch = 0; ch < C; ++ch) {
+        float v = k0[off + ch] * w;
+        if (ch >= k0_skip) f[ch - k0_skip] += v;
+        if (k0_raw) k0_raw[(size_t)m * C + ch] += v;
+      }
+  }
+  int o = C - k0_skip;
+  for (int a = 0; a < 3; ++a) {
+    float ta = pp_div(pp_sub(p[a], sc.mn[a]), pp_sub(sc.mx[a], sc.mn[a]));
+    f[o + a] = ta;
+    float fr = 1.f;
+    for (int k = 0; k < Lp; ++k) {
+      float s, c;
+      sincosf(ta * fr, &s, &c);
+      float w = pe_w ? pe_w[k] : 1.f;
+      f[o + 3 + a * Lp + k] = s * w;
+      f[o + 3 + 3 * Lp + a * Lp + k] = c * w;
+      fr *= 2.f;
+    }
+  }
+  o += 3 + 6 * Lp;
+  int r = ray_id[m];
+  for (int a = 0; a < 3; ++a) {
+    float va = viewdirs[r * 3 + a];
+    f[o + a] = va;
+    float fr = 1.f;
+    for (int k = 0; k < Lv; ++k) {
+      float s, c;
+      sincosf(va * fr, &s, &c);
+      float w = pe_w ? pe_w[Lp + k] : 1.f;
+      f[o + 3 + a * Lv + k] = s * w;
+      f[o + 3 + 3 * Lv + a * Lv + k] = c * w;
+      fr *= 2.f;
+    }
+  }
+  o += 3 + 6 * Lv;
+  if (gradient) {
+    float g[3] = {gradient[m * 3], gradient[m * 3 + 1], gradient[m * 3 + 2]};
+    float gn = pp_norm3c(g[0], g[1], g[2]) + 1e-5f;
+    for (int a = 0; a < 3; ++a) f[o + a] = g[a] / gn;
+  }
+}
+
+// backward of the generic builder w.r.t. the k0 grid only (the DVGO twin has no pose / point gradients):
+// feat_grad[M,ld] (+ optional k0_raw_grad[M,C] for the diffuse channels) -> k0_grad (atomic +=). 16 lanes per sample.
+__global__ __launch_bounds__(256) void k_feat_generic_bwd_k0(SceneDev sc, const float* __restrict__ pts,
+                                                             const uint8_t* __restrict__ sel, int k0_skip, int ld,
+                                                             const int32_t* __restrict__ count, int capacity,
+                                                             const float* __restrict__ feat_grad,
+                                                             const float* __restrict__ k0_raw_grad,
+                                                             float* __restrict__ k0_grad) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int m = t >> 4, ch = t & 15;
+  int M = min(count[0], capacity);
+  if (m >= M || ch >= sc.C) return;
+  if (sel && !sel[m]) return;
+  float g = (ch >= k0_skip) ? feat_grad[(size_t)m * ld + ch - k0_skip] : 0.f;
+  if (k0_raw_grad) g += k0_raw_grad[(size_t)m * sc.C + ch];
+  if (g == 0.f) return;
+  float p[3] = {pts[m * 3], pts[m * 3 + 1], pts[m * 3 + 2]};
+  K0Tri tr;
+  k0_setup(sc, p, tr);
+  for (int c = 0; c < 8; ++c) {
+    size_t off; float w;
+    if (k0_corner(sc, tr, c, off, w)) atomicAdd(&k0_grad[off + ch], w * g);
+  }
+}
+
+extern "C" int pp_feat_generic_fwd(const pp_scene* sc, const float* k0_cl, const float* pts, const float* viewdirs,
+                                   const int32_t* ray_id, const float* gradient, const float* pe_w, const uint8_t* sel,
+                                   int32_t k0_skip, int32_t ld, const int32_t* count, int32_t capacity, float* feat,
+                                   float* k0_raw, void* stream) {
+  PP_REQUIRE(sc && k0_cl && pts && viewdirs && ray_id && count && feat, "null pointer");
+  PP_REQUIRE(capacity > 0 && sc->k0_dim <= 16, "capacity<=0 or k0_dim>16");
+  int width = sc->k0_dim - k0_skip + 3 + 6 * sc->pos_pe + 3 + 6 * sc->view_pe + (gradient ? 3 : 0);
+  PP_REQUIRE(ld % 32 == 0 && width <= ld && k0_skip >= 0 && k0_skip <= sc->k0_dim, "feature width does not fit ld (multiple of 32)");
+  hipLaunchKernelGGL(k_feat_generic_fwd, dim3(pp_div_up(capacity, 256)), dim3(256), 0, pp_stream(stream), pp_scene_dev(sc),
+                     k0_cl, pts, viewdirs, ray_id, gradient, pe_w, sel, k0_skip, ld, count, capacity, feat, k0_raw);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_feat_generic_bwd_k0(const pp_scene* sc, const float* pts, const uint8_t* sel, int32_t k0_skip, int32_t ld,
+                                      const int32_t* count, int32_t capacity, const float* feat_grad,
+                                      const float* k0_raw_grad, float* k0_grad_cl, void* stream) {
+  PP_REQUIRE(sc && pts && count && feat_grad && k0_grad_cl, "null pointer");
+  PP_REQUIRE(capacity > 0 && sc->k0_dim <= 16, "capacity<=0 or k0_dim>16");
+  hipLaunchKernelGGL(k_feat_generic_bwd_k0, dim3(pp_div_up(capacity * 16, 256)), dim3(256), 0, pp_stream(stream),
+                     pp_scene_dev(sc), pts, sel, k0_skip, ld, count, capacity, feat_grad, k0_raw_grad, k0_grad_cl);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
 extern "C" int pp_color_feat_fwd(const pp_scene* sc, const float* k0_cl, const float* pts, const float* viewdirs,
                                  const int32_t* ray_id, const float* gradient, const float* pe_w,
                                  const int32_t* count, int32_t capacity, float* feat, void* stream) {

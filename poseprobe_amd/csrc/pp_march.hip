@@ -5,7 +5,7 @@
 // coalesced (the reference walks each ray from a single thread).
 #include "pp_common.h"
 
-template <bool FUSED>
+template <bool FUSED, bool DVGO>
 __global__ __launch_bounds__(256) void k_march_fwd(const float* __restrict__ alpha, const float* __restrict__ rgb,
                                                    const float* __restrict__ step_w, const float* __restrict__ nrm_in,
                                                    const int32_t* __restrict__ ray_start, int n_rays, float bg,
@@ -31,8 +31,12 @@ __global__ __launch_bounds__(256) void k_march_fwd(const float* __restrict__ alp
       for (int j = 0; j < n; ++j) {
         float aj = __shfl(a, j, 64);
         if (lane == j) { myT = Tc; myw = Tc * aj; }
-        Tc = (float)((double)Tc * (1.0 - (double)aj));
-        if ((double)Tc < 1e-3) { stop = c0 + j + 1; stopped = true; break; }
+        if (DVGO) {           // cumprod_exclusive: p.clamp_min(1e-10).cumprod(-1), fp32, no early stop (dvgo_ori.py:478-485)
+          Tc = Tc * fmaxf(1.f - aj, 1e-10f);
+        } else {
+          Tc = (float)((double)Tc * (1.0 - (double)aj));
+          if ((double)Tc < 1e-3) { stop = c0 + j + 1; stopped = true; break; }
+        }
       }
     }
     if (i < e) {
@@ -125,7 +129,7 @@ extern "C" int pp_alpha2weight_fwd(const float* alpha, const int32_t* ray_start,
                                    float* T, float* alphainv_last, int32_t* i_end, void* stream) {
   PP_REQUIRE(alpha && ray_start && weights && T && alphainv_last && i_end, "null pointer");
   PP_REQUIRE(n_rays > 0, "n_rays<=0");
-  hipLaunchKernelGGL((k_march_fwd<false>), dim3(pp_div_up(n_rays, 4)), dim3(256), 0, pp_stream(stream), alpha, nullptr,
+  hipLaunchKernelGGL((k_march_fwd<false, false>), dim3(pp_div_up(n_rays, 4)), dim3(256), 0, pp_stream(stream), alpha, nullptr,
                      nullptr, nullptr, ray_start, n_rays, 0.f, weights, T, alphainv_last, i_end, nullptr, nullptr,
                      nullptr, nullptr, nullptr);
   PP_CHECK_LAUNCH();
@@ -151,7 +155,7 @@ extern "C" int pp_march_fwd(const float* alpha, const float* rgb, const float* s
                             float* cum_weights, float* depth_acc, float* normal_marched, void* stream) {
   PP_REQUIRE(alpha && rgb && ray_start && weights && T && alphainv_last && i_end && cum_weights, "null pointer");
   PP_REQUIRE(n_rays > 0, "n_rays<=0");
-  hipLaunchKernelGGL((k_march_fwd<true>), dim3(pp_div_up(n_rays, 4)), dim3(256), 0, pp_stream(stream), alpha, rgb,
+  hipLaunchKernelGGL((k_march_fwd<true, false>), dim3(pp_div_up(n_rays, 4)), dim3(256), 0, pp_stream(stream), alpha, rgb,
                      step_w, nrm_in, ray_start, n_rays, bg, weights, T, alphainv_last, i_end, rgb_marched, rgb_pre,
                      cum_weights, depth_acc, normal_marched);
   PP_CHECK_LAUNCH();
@@ -234,6 +238,20 @@ extern "C" int pp_sdf_first_crossing(const float* sdf, const int32_t* ray_start,
   PP_REQUIRE(n_rays > 0 && n_samples >= 2 && n_samples <= PP_MAX_S, "need n_rays>0 and 2<=n_samples<=1024");
   hipLaunchKernelGGL(k_first_crossing, dim3(pp_div_up(n_rays, 4)), dim3(256), 0, pp_stream(stream), sdf, ray_start, step_k,
                      n_rays, n_samples, dist, t_min, rays_o, rays_d, sdf_dense, pts, mask, zval);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+// DirectVoxGO compositing (lib/dvgo_ori.py:478-489, :361-366): exclusive cumprod of clamp_min(1-alpha, 1e-10) without
+// early termination; rgb_marched = sum w*rgb + alphainv_last*bg (clamped), depth_acc = sum w*step_w.
+extern "C" int pp_march_dvgo_fwd(const float* alpha, const float* rgb, const float* step_w, const int32_t* ray_start,
+                                 int32_t n_rays, float* weights, float* T, float* alphainv_last, int32_t* i_end,
+                                 float* rgb_acc, float* cum_weights, float* depth_acc, void* stream) {
+  PP_REQUIRE(alpha && ray_start && weights && T && alphainv_last && i_end && cum_weights, "null pointer");
+  PP_REQUIRE(n_rays > 0, "n_rays<=0");
+  hipLaunchKernelGGL((k_march_fwd<true, true>), dim3(pp_div_up(n_rays, 4)), dim3(256), 0, pp_stream(stream), alpha, rgb,
+                     step_w, nullptr, ray_start, n_rays, 0.f, weights, T, alphainv_last, i_end, nullptr, rgb_acc,
+                     cum_weights, depth_acc, nullptr);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }

@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256) void k_warp_l0_bwd_w(const float* __restrict__
 // rgbnet output layer (128 -> 3) + sigmoid: 16 lanes per sample.
 __global__ __launch_bounds__(256) void k_rgb_out_fwd(const float* __restrict__ W3, const float* __restrict__ b3,
                                                      const float* __restrict__ H3, const int32_t* __restrict__ count,
-                                                     int capacity, float* __restrict__ rgb) {
+                                                     int capacity, const float* __restrict__ logit_add, int add_ld,
+                                                     float* __restrict__ rgb) {
   int M = min(count[0], capacity);
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int m = t >> 4, sub = t & 15;
@@ -418,14 +419,14 @@ __global__ __launch_bounds__(256) void k_rgb_out_fwd(const float* __restrict__ W
     acc[o] = s;
   }
   if (live && sub == 0)
-    for (int o = 0; o < 3; ++o) rgb[m * 3 + o] = pp_sigmoid(acc[o] + b3[o]);
+    for (int o = 0; o < 3; ++o) rgb[m * 3 + o] = pp_sigmoid(acc[o] + b3[o] + (logit_add ? logit_add[(size_t)m * add_ld + o] : 0.f));
 }
 
 __global__ __launch_bounds__(256) void k_rgb_out_bwd(const float* __restrict__ W3, const float* __restrict__ H3,
                                                      const float* __restrict__ rgb, const float* __restrict__ rgb_grad,
                                                      const int32_t* __restrict__ count, int capacity,
                                                      float* __restrict__ Ybar, float* __restrict__ W3bar,
-                                                     float* __restrict__ b3bar) {
+                                                     float* __restrict__ b3bar, float* __restrict__ logit_grad, int lg_ld) {
   __shared__ float red[3 * 128];
   int M = min(count[0], capacity);
   int m0 = blockIdx.x * STRIP;
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256) void k_rgb_out_bwd(const float* __restrict__ W
     wacc[0] += gl[0] * x; wacc[1] += gl[1] * x; wacc[2] += gl[2] * x;
     float hb = gl[0] * w[0] + gl[1] * w[1] + gl[2] * w[2];
     Ybar[(size_t)m * 128 + j] = (x > 0.f) ? hb : 0.f;
-    if (j < 3) bacc += gl[j];
+    if (j < 3) { bacc += gl[j]; if (logit_grad) logit_grad[(size_t)m * lg_ld + j] = gl[j]; }
   }
   if (h == 1) { for (int o = 0; o < 3; ++o) red[o * 128 + j] = wacc[o]; }
   __syncthreads();
@@ -478,58 +479,81 @@ static inline int gemm_grid(int rows, int bm) { int t = pp_div_up(rows, bm); ret
 #define PP_GEMM_BM 64
 #endif
 
-extern "C" int pp_rgbnet_fwd(const float* params, const float* feat, const int32_t* count, int32_t capacity,
-                             float* acts, float* rgb, void* stream) {
-  PP_REQUIRE(params && feat && count && acts && rgb, "null pointer");
-  PP_REQUIRE(capacity > 0, "capacity<=0");
+// Generic ReLU MLP  in_ld -> 128 -> ... -> 128 -> 3 (+ optional sigmoid), n_gemm = number of 128-wide hidden layers.
+// Parameter block: W0[128*in_ld] b0[128] | (W[128*128] b[128]) x (n_gemm-1) | Wout[3*128] bout[3].
+static inline size_t mlp_off_hidden(int in_ld, int l) { return (size_t)128 * in_ld + 128 + (size_t)(l - 1) * (128 * 128 + 128); }
+static inline size_t mlp_off_out(int in_ld, int n_gemm) { return mlp_off_hidden(in_ld, n_gemm); }
+
+extern "C" int pp_mlp_fwd(const float* params, const float* feat, int32_t in_ld, int32_t n_gemm, const int32_t* count,
+                          int32_t capacity, const float* logit_add, int32_t logit_add_ld, float* acts, float* out,
+                          void* stream) {
+  PP_REQUIRE(params && feat && count && acts && out, "null pointer");
+  PP_REQUIRE(capacity > 0 && in_ld % 32 == 0 && in_ld <= 128 && n_gemm >= 1 && n_gemm <= 8, "bad sizes");
   hipStream_t st = pp_stream(stream);
   const size_t LS = (size_t)capacity * 128;
   dim3 g(gemm_grid(capacity, PP_GEMM_BM)), b(256);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1, PP_GEMM_BM>), g, b, 0, st, feat, 64, params + RG_W0, 64, 64, 128,
-                     params + RG_B0, nullptr, 0, acts, 128, count, 1, capacity);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1, PP_GEMM_BM>), g, b, 0, st, acts, 128, params + RG_W1, 128, 128, 128,
-                     params + RG_B1, nullptr, 0, acts + LS, 128, count, 1, capacity);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1, PP_GEMM_BM>), g, b, 0, st, acts + LS, 128, params + RG_W2, 128, 128, 128,
-                     params + RG_B2, nullptr, 0, acts + 2 * LS, 128, count, 1, capacity);
-  hipLaunchKernelGGL(k_rgb_out_fwd, dim3(pp_div_up(capacity * 16, 256)), b, 0, st, params + RG_W3, params + RG_B3,
-                     acts + 2 * LS, count, capacity, rgb);
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1, PP_GEMM_BM>), g, b, 0, st, feat, in_ld, params, in_ld, in_ld, 128,
+                     params + (size_t)128 * in_ld, nullptr, 0, acts, 128, count, 1, capacity);
+  for (int l = 1; l < n_gemm; ++l) {
+    const float* W = params + mlp_off_hidden(in_ld, l);
+    hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1, PP_GEMM_BM>), g, b, 0, st, acts + (l - 1) * LS, 128, W, 128, 128, 128,
+                       W + 128 * 128, nullptr, 0, acts + l * LS, 128, count, 1, capacity);
+  }
+  const float* Wo = params + mlp_off_out(in_ld, n_gemm);
+  hipLaunchKernelGGL(k_rgb_out_fwd, dim3(pp_div_up(capacity * 16, 256)), b, 0, st, Wo, Wo + 3 * 128,
+                     acts + (n_gemm - 1) * LS, count, capacity, logit_add, logit_add_ld, out);
   PP_CHECK_LAUNCH();
   return PP_OK;
+}
+
+extern "C" int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld, int32_t n_gemm, const float* acts,
+                          const float* out, const float* out_grad, const int32_t* count, int32_t capacity,
+                          float* scratch, float* params_grad, float* feat_grad, float* logit_add_grad,
+                          int32_t logit_add_ld, void* stream) {
+  PP_REQUIRE(params && feat && acts && out && out_grad && count && scratch && params_grad, "null pointer");
+  PP_REQUIRE(capacity > 0 && in_ld % 32 == 0 && in_ld <= 128 && n_gemm >= 1 && n_gemm <= 8, "bad sizes");
+  hipStream_t st = pp_stream(stream);
+  const size_t LS = (size_t)capacity * 128;
+  float* cur = scratch;
+  float* nxt = scratch + LS;
+  float* wt = scratch + 2 * LS;      // one transposed weight matrix at a time (128*128 floats)
+  dim3 g(gemm_grid(capacity, PP_GEMM_BM)), gt(pp_div_up(capacity, TN_ROWS)), b(256);
+  const size_t oo = mlp_off_out(in_ld, n_gemm);
+  hipLaunchKernelGGL(k_rgb_out_bwd, dim3(pp_div_up(capacity, STRIP)), b, 0, st, params + oo, acts + (n_gemm - 1) * LS, out,
+                     out_grad, count, capacity, cur, params_grad + oo, params_grad + oo + 3 * 128, logit_add_grad,
+                     logit_add_ld);
+  for (int l = n_gemm - 1; l >= 1; --l) {
+    const size_t ow = mlp_off_hidden(in_ld, l);
+    hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + ow, wt, 128, 128);
+    hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, cur, acts + (l - 1) * LS, 128, 128, params_grad + ow, 128,
+                       params_grad + ow + 128 * 128, count, 1, capacity, TN_ROWS);
+    hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 1, PP_GEMM_BM>), g, b, 0, st, cur, 128, wt, 128, 128, 128, nullptr,
+                       acts + (l - 1) * LS, 128, nxt, 128, count, 1, capacity);
+    float* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, cur, feat, in_ld, in_ld, params_grad, in_ld,
+                     params_grad + (size_t)128 * in_ld, count, 1, capacity, TN_ROWS);
+  if (feat_grad) {
+    hipLaunchKernelGGL(k_transpose, dim3(pp_div_up(128 * in_ld, 256)), b, 0, st, params, wt, 128, in_ld);
+    hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_PLAIN, 1, PP_GEMM_BM>), g, b, 0, st, cur, 128, wt, 128, 128, in_ld, nullptr,
+                       nullptr, 0, feat_grad, in_ld, count, 1, capacity);
+  }
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+// rgbnet of the Voxurf configuration = generic MLP with a 64-wide (57 used) input and three 128-wide layers.
+extern "C" int pp_rgbnet_fwd(const float* params, const float* feat, const int32_t* count, int32_t capacity,
+                             float* acts, float* rgb, void* stream) {
+  return pp_mlp_fwd(params, feat, 64, 3, count, capacity, nullptr, 0, acts, rgb, stream);
 }
 
 extern "C" int pp_rgbnet_bwd(const float* params, const float* feat, const float* acts, const float* rgb,
                              const float* rgb_grad, const int32_t* count, int32_t capacity, float* scratch,
                              float* params_grad, float* feat_grad, void* stream) {
-  PP_REQUIRE(params && feat && acts && rgb && rgb_grad && count && scratch && params_grad && feat_grad, "null pointer");
-  PP_REQUIRE(capacity > 0, "capacity<=0");
-  hipStream_t st = pp_stream(stream);
-  const size_t LS = (size_t)capacity * 128;
-  float* s0 = scratch;
-  float* s1 = scratch + LS;
-  dim3 g(gemm_grid(capacity, PP_GEMM_BM)), gt(pp_div_up(capacity, TN_ROWS)), b(256);
-  hipLaunchKernelGGL(k_rgb_out_bwd, dim3(pp_div_up(capacity, STRIP)), b, 0, st, params + RG_W3, acts + 2 * LS, rgb,
-                     rgb_grad, count, capacity, s0, params_grad + RG_W3, params_grad + RG_B3);
-  float* wt = scratch + 2 * LS;          // transposed weights W2^T, W1^T, W0^T
-  hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + RG_W2, wt, 128, 128);
-  hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + RG_W1, wt + 16384, 128, 128);
-  hipLaunchKernelGGL(k_transpose, dim3(32), b, 0, st, params + RG_W0, wt + 32768, 128, 64);
-  // layer 2
-  hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, s0, acts + LS, 128, 128, params_grad + RG_W2, 128,
-                     params_grad + RG_B2, count, 1, capacity, TN_ROWS);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 1, PP_GEMM_BM>), g, b, 0, st, s0, 128, wt, 128, 128, 128, nullptr,
-                     acts + LS, 128, s1, 128, count, 1, capacity);
-  // layer 1
-  hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, s1, acts, 128, 128, params_grad + RG_W1, 128, params_grad + RG_B1,
-                     count, 1, capacity, TN_ROWS);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 1, PP_GEMM_BM>), g, b, 0, st, s1, 128, wt + 16384, 128, 128, 128, nullptr,
-                     acts, 128, s0, 128, count, 1, capacity);
-  // layer 0
-  hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, s0, feat, 64, 64, params_grad + RG_W0, 64, params_grad + RG_B0,
-                     count, 1, capacity, TN_ROWS);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_PLAIN, 1, PP_GEMM_BM>), g, b, 0, st, s0, 128, wt + 32768, 128, 128, 64, nullptr,
-                     nullptr, 0, feat_grad, 64, count, 1, capacity);
-  PP_CHECK_LAUNCH();
-  return PP_OK;
+  PP_REQUIRE(feat_grad, "null pointer");
+  return pp_mlp_bwd(params, feat, 64, 3, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad, nullptr, 0,
+                    stream);
 }
 
 extern "C" int pp_warp_fwd(const float* params, const float* pts, const int32_t* count, int32_t capacity,

@@ -224,3 +224,29 @@ def grid_tv_grad(p, size, channels, scale, g_scalar, grad):
 def sdf_first_crossing(sdf, ray_start, step_k, n_rays, n_samples, dist, t_min, rays_o, rays_d, sdf_dense, pts, mask, zval):
     _lib.call('pp_sdf_first_crossing', _f(sdf), _i(ray_start), _i(step_k), n_rays, n_samples, float(dist), _f(t_min),
               _f(rays_o), _f(rays_d), _f(sdf_dense), _f(pts), _ptr(mask, torch.uint8), _f(zval), _stream())
+
+
+def feat_generic_fwd(sc, k0_cl, pts, viewdirs, ray_id, gradient, pe_w, sel, k0_skip, ld, count, capacity, feat, k0_raw):
+    _lib.call('pp_feat_generic_fwd', ctypes.byref(sc), _f(k0_cl), _f(pts), _f(viewdirs), _i(ray_id), _f(gradient), _f(pe_w),
+              _ptr(sel, torch.uint8), int(k0_skip), int(ld), _i(count), capacity, _f(feat), _f(k0_raw), _stream())
+
+
+def feat_generic_bwd_k0(sc, pts, sel, k0_skip, ld, count, capacity, feat_grad, k0_raw_grad, k0_grad_cl):
+    _lib.call('pp_feat_generic_bwd_k0', ctypes.byref(sc), _f(pts), _ptr(sel, torch.uint8), int(k0_skip), int(ld), _i(count),
+              capacity, _f(feat_grad), _f(k0_raw_grad), _f(k0_grad_cl), _stream())
+
+
+def mlp_fwd(params, feat, in_ld, n_gemm, count, capacity, logit_add, logit_add_ld, acts, out):
+    _lib.call('pp_mlp_fwd', _f(params), _f(feat), int(in_ld), int(n_gemm), _i(count), capacity, _f(logit_add),
+              int(logit_add_ld), _f(acts), _f(out), _stream())
+
+
+def mlp_bwd(params, feat, in_ld, n_gemm, acts, out, out_grad, count, capacity, scratch, params_grad, feat_grad,
+            logit_add_grad, logit_add_ld):
+    _lib.call('pp_mlp_bwd', _f(params), _f(feat), int(in_ld), int(n_gemm), _f(acts), _f(out), _f(out_grad), _i(count),
+              capacity, _f(scratch), _f(params_grad), _f(feat_grad), _f(logit_add_grad), int(logit_add_ld), _stream())
+
+
+def march_dvgo_fwd(alpha, rgb, step_w, ray_start, n_rays, weights, T, alphainv_last, i_end, rgb_acc, cum_weights, depth_acc):
+    _lib.call('pp_march_dvgo_fwd', _f(alpha), _f(rgb), _f(step_w), _i(ray_start), n_rays, _f(weights), _f(T),
+              _f(alphainv_last), _i(i_end), _f(rgb_acc), _f(cum_weights), _f(depth_acc), _stream())

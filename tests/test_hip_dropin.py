@@ -166,3 +166,41 @@ def test_surface_point_queries_match_reference():
     assert_close(c(pts), d['q_render_pts'], rtol=1e-4, atol=2e-5, name='render pts')
     pts.sum().backward()                 # differentiable w.r.t. the rays (-> pose)
     assert torch.isfinite(ro_g.grad).all() and float(ro_g.grad.abs().sum()) > 0
+
+
+def test_directvoxgo_twin_matches_reference():
+    """DirectVoxGO.forward (lib/dvgo_ori.py:289-379) + gradients of density / k0 / rgbnet vs the reference's golden."""
+    from poseprobe_amd import synthetic as syn
+    from poseprobe_amd.dvgo_ori import DirectVoxGO
+    d = load('dvgo_g16.npz')
+    G = int(d['G'])
+    m = DirectVoxGO(syn.XYZ_MIN, syn.XYZ_MAX, num_voxels=G ** 3, num_voxels_base=G ** 3, alpha_init=1e-2, rgbnet_dim=12,
+                    rgbnet_direct=True, rgbnet_depth=3, rgbnet_width=128, posbase_pe=5, viewbase_pe=4,
+                    fast_color_thres=1e-4)
+    sd = m.state_dict()
+    assert {'xyz_min', 'xyz_max', 'density', 'k0', 'posfreq', 'viewfreq', 'rgbnet.0.weight', 'rgbnet.0.bias',
+            'rgbnet.2.0.weight', 'rgbnet.2.0.bias', 'rgbnet.3.weight', 'rgbnet.3.bias'} == set(sd.keys())
+    sd['density'], sd['k0'] = torch.tensor(d['density']), torch.tensor(d['k0'])
+    for li, key in enumerate(['rgbnet.0', 'rgbnet.2.0', 'rgbnet.3']):
+        sd[key + '.weight'], sd[key + '.bias'] = torch.tensor(d[f'rgbnet.{li}.weight']), torch.tensor(d[f'rgbnet.{li}.bias'])
+    m.load_state_dict(sd)
+    m = m.cuda()
+    ro, rd, vd = (torch.tensor(d[k]).cuda() for k in ('rays_o', 'rays_d', 'viewdirs'))
+    out = m(ro, rd, vd, global_step=5, near=0.24, far=4.8, bg=1, stepsize=0.5, inverse_y=True, flip_x=False, flip_y=False,
+            jitter=torch.tensor(d['jitter']))
+    c = lambda t: t.detach().cpu().numpy()
+    assert np.array_equal(c(out['mask_outbbox']), d['out.mask_outbbox'])
+    assert (c(out['mask']) != d['out.mask']).mean() < 1e-3       # weights within rounding of the 1e-4 threshold
+    for k in ('alphainv_cum', 'weights', 'rgb_marched', 'raw_alpha', 'depth'):
+        assert_close(c(out[k]), d['out.' + k], rtol=1e-4, atol=1e-5, name=k)
+    same = c(out['mask']) == d['out.mask']
+    assert_close(c(out['raw_rgb'])[same], d['out.raw_rgb'][same], rtol=1e-4, atol=1e-5, name='raw_rgb')
+    loss = ((out['rgb_marched'] - torch.tensor(d['target']).cuda()) ** 2).mean()
+    assert_close(c(loss), d['loss'], rtol=1e-4, name='loss')
+    loss.backward()
+    tol = dict(rtol=1e-3, scaled=2e-5)
+    assert_close(c(m.density.grad), d['grad_density'], atol=1e-9, name='g.density', **tol)
+    assert_close(c(m.k0.grad), d['grad_k0'], atol=1e-9, name='g.k0', **tol)
+    for li, lin in enumerate([m.rgbnet[0], m.rgbnet[2][0], m.rgbnet[3]]):
+        assert_close(c(lin.weight.grad), d[f'grad.rgbnet.{li}.weight'], atol=1e-9, name=f'g.rgbnet{li}.W', **tol)
+        assert_close(c(lin.bias.grad), d[f'grad.rgbnet.{li}.bias'], atol=1e-9, name=f'g.rgbnet{li}.b', **tol)
