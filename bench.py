@@ -142,12 +142,27 @@ def main():
         ev.append((e0, e1))
 
     ops.grid_tv_adam_step = timed_grid_step
+    # second roofline: the two MLPs on the matrix cores (fp32 MFMA), timed the same way
+    mlp_ev = []
+
+    def timed(fn):
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*a, **k)
+            e1.record()
+            mlp_ev.append((e0, e1))
+        return wrapper
+
+    for name in ('warp_fwd', 'warp_bwd', 'rgbnet_fwd', 'rgbnet_bwd'):
+        setattr(ops, name, timed(getattr(ops, name)))
 
     gs = 10
     for s in range(args.warmup):
         eng.train_step(idx_all[s], jit_all[s], gs + s)
     barrier()
     ev.clear()
+    mlp_ev.clear()
     t0 = time.perf_counter()
     for s in range(args.warmup, total):
         eng.train_step(idx_all[s], jit_all[s], gs + s)
@@ -163,6 +178,11 @@ def main():
     X, Y, Z = cfg.world_size
     grid_bytes = GRID_BYTES_PER_VOXEL * (xe - xb) * Y * Z
     achieved = grid_bytes / (grid_ms * 1e-3) / 1e9
+    # MFMA-shaped work per sample: warp hidden GEMMs 3 layers x 4 rows x 2*128*128 x (fwd + 2 bwd),
+    # rgbnet (64*128 + 2*128*128) x 2 x (fwd + 2 bwd)
+    flop_per_sample = 3 * (3 * 4 * 2 * 128 * 128) + 3 * (2 * (64 * 128 + 2 * 128 * 128))
+    mlp_ms = float(np.sum([a.elapsed_time(b) for a, b in mlp_ev])) / max(args.steps, 1) if mlp_ev else float('nan')
+    mlp_tflops = flop_per_sample * M / (mlp_ms * 1e-3) / 1e12
 
     if rank == 0:
         out = {
@@ -176,6 +196,9 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': 'k_grid_tv_adam (fused TV-grad + Adam + zero-grad over k0)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': pmc_traffic(G, (xe - xb) * Y * Z), 'ms_per_launch': grid_ms, 'algorithmic_bytes_per_launch': grid_bytes},
+            'roofline_mfma': {'bound': 'mfma', 'kernel': 'warp + rgbnet MLP chains (k_gemm128 / k_gemm_tn, fp32 MFMA 32x32x2)',
+                              'achieved': mlp_tflops, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': mlp_tflops / 157.3,
+                              'ms_per_step': mlp_ms, 'flop_per_sample': flop_per_sample},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(G, H, W, V, N, views, args.cpu_budget)

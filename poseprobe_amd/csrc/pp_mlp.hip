@@ -173,11 +173,11 @@ __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ src
 template <int COLS>
 __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ Y, const float* __restrict__ X, int ldx,
                                                  int Kx, float* __restrict__ Wbar, int ldwb, float* __restrict__ bbar,
-                                                 const int32_t* __restrict__ count, int rmul, int rcap,
-                                                 int rows_per_wg) {
+                                                 const int32_t* __restrict__ count, int rmul, int rcap) {
   __shared__ float Ys[32 * 128];
   __shared__ float Xs[32 * 128];
   const int R = min(count[0] * rmul, rcap);
+  const int rows_per_wg = ((R + (int)gridDim.x - 1) / (int)gridDim.x + 31) & ~31;   // multiple of 32 (and of COLS)
   const int rb = blockIdx.x * rows_per_wg;
   if (rb >= R) return;
   const int re = min(rb + rows_per_wg, R);
@@ -472,7 +472,9 @@ __global__ __launch_bounds__(256) void k_rgb_out_bwd(const float* __restrict__ W
 #define WP_W4 (WP_B3 + 128)
 #define WP_B4 (WP_W4 + 4 * 128)
 
-static const int TN_ROWS = 512;
+// weight-gradient GEMM: a FIXED number of work-groups splits the (device-side) row count evenly; measured optimum on
+// MI355X ~ 450 work-groups (more: the 64 KB of contended atomics per work-group dominates; fewer: idle CUs).
+static const int TN_WGS = 448;
 static const int GEMM_MAX_WG = 256 * 5;     // 5 resident work-groups per CU at BM=64 (25 KB LDS, 90 regs)
 static inline int gemm_grid(int rows, int bm) { int t = pp_div_up(rows, bm); return t < GEMM_MAX_WG ? t : GEMM_MAX_WG; }
 #ifndef PP_GEMM_BM
@@ -517,7 +519,7 @@ extern "C" int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld,
   float* cur = scratch;
   float* nxt = scratch + LS;
   float* wt = scratch + 2 * LS;      // one transposed weight matrix at a time (128*128 floats)
-  dim3 g(gemm_grid(capacity, PP_GEMM_BM)), gt(pp_div_up(capacity, TN_ROWS)), b(256);
+  dim3 g(gemm_grid(capacity, PP_GEMM_BM)), gt(TN_WGS), b(256);
   const size_t oo = mlp_off_out(in_ld, n_gemm);
   hipLaunchKernelGGL(k_rgb_out_bwd, dim3(pp_div_up(capacity, STRIP)), b, 0, st, params + oo, acts + (n_gemm - 1) * LS, out,
                      out_grad, count, capacity, cur, params_grad + oo, params_grad + oo + 3 * 128, logit_add_grad,
@@ -526,13 +528,13 @@ extern "C" int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld,
     const size_t ow = mlp_off_hidden(in_ld, l);
     hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + ow, wt, 128, 128);
     hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, cur, acts + (l - 1) * LS, 128, 128, params_grad + ow, 128,
-                       params_grad + ow + 128 * 128, count, 1, capacity, TN_ROWS);
+                       params_grad + ow + 128 * 128, count, 1, capacity);
     hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 1, PP_GEMM_BM>), g, b, 0, st, cur, 128, wt, 128, 128, 128, nullptr,
                        acts + (l - 1) * LS, 128, nxt, 128, count, 1, capacity);
     float* tmp = cur; cur = nxt; nxt = tmp;
   }
   hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, cur, feat, in_ld, in_ld, params_grad, in_ld,
-                     params_grad + (size_t)128 * in_ld, count, 1, capacity, TN_ROWS);
+                     params_grad + (size_t)128 * in_ld, count, 1, capacity);
   if (feat_grad) {
     hipLaunchKernelGGL(k_transpose, dim3(pp_div_up(128 * in_ld, 256)), b, 0, st, params, wt, 128, in_ld);
     hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_PLAIN, 1, PP_GEMM_BM>), g, b, 0, st, cur, 128, wt, 128, 128, in_ld, nullptr,
@@ -588,7 +590,7 @@ extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* a
   const size_t LS = (size_t)rcap * 128;
   float* s0 = scratch;
   float* s1 = scratch + LS;
-  dim3 g(gemm_grid(rcap, PP_GEMM_BM)), gt(pp_div_up(rcap, TN_ROWS)), b(256);
+  dim3 g(gemm_grid(rcap, PP_GEMM_BM)), gt(TN_WGS), b(256);
   hipLaunchKernelGGL(k_warp_l4_bwd, dim3(pp_div_up(capacity, STRIP)), b, 0, st, params + WP_W4, acts + 3 * LS, out_grad,
                      count, capacity, out_range, s0, params_grad + WP_W4, params_grad + WP_B4);
   float* wt = scratch + 2 * LS;          // transposed weights W3^T, W2^T, W1^T
@@ -597,17 +599,17 @@ extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* a
   hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + WP_W1, wt + 32768, 128, 128);
   // layer 3
   hipLaunchKernelGGL((k_gemm_tn<4>), gt, b, 0, st, s0, acts + 2 * LS, 128, 128, params_grad + WP_W3, 128,
-                     params_grad + WP_B3, count, 4, rcap, TN_ROWS);
+                     params_grad + WP_B3, count, 4, rcap);
   hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 4, PP_GEMM_BM>), g, b, 0, st, s0, 128, wt, 128, 128, 128, nullptr,
                      acts + 2 * LS, 128, s1, 128, count, 4, rcap);
   // layer 2
   hipLaunchKernelGGL((k_gemm_tn<4>), gt, b, 0, st, s1, acts + LS, 128, 128, params_grad + WP_W2, 128,
-                     params_grad + WP_B2, count, 4, rcap, TN_ROWS);
+                     params_grad + WP_B2, count, 4, rcap);
   hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 4, PP_GEMM_BM>), g, b, 0, st, s1, 128, wt + 16384, 128, 128, 128, nullptr,
                      acts + LS, 128, s0, 128, count, 4, rcap);
   // layer 1
   hipLaunchKernelGGL((k_gemm_tn<4>), gt, b, 0, st, s0, acts, 128, 128, params_grad + WP_W1, 128, params_grad + WP_B1,
-                     count, 4, rcap, TN_ROWS);
+                     count, 4, rcap);
   hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 4, PP_GEMM_BM>), g, b, 0, st, s0, 128, wt + 32768, 128, 128, 128, nullptr,
                      acts, 128, s1, 128, count, 4, rcap);
   // layer 0
