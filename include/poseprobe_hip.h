@@ -162,6 +162,12 @@ int pp_color_feat_bwd(const pp_scene* sc, const float* k0_cl, const float* pts, 
                       int32_t capacity, const float* feat_grad, float* k0_grad_cl, float* pts_grad,
                       float* gradient_grad, float* viewdir_grad_s, void* stream);
 
+/* Optional caller-owned context (one auxiliary HIP stream + events).  When passed to the MLP backward entry points the
+ * weight-gradient GEMM of every layer is forked onto the auxiliary stream and runs beside the data-gradient GEMM
+ * (fork / join are event edges: the sequence stays hipGraph-capturable).  NULL = strictly sequential on `stream`. */
+int pp_context_create(void** ctx);
+int pp_context_destroy(void* ctx);
+
 /* ---------------------------------------------------------------- MLPs on the matrix cores (fp32 MFMA).
  * rgbnet (voxurf_coarse.py:208-216, :1032-1033): 64(57)->128->128->128->3, sigmoid.
  * Parameter block layout (floats): W0[128*64] b0[128] W1[128*128] b1[128] W2[128*128] b2[128] W3[3*128] b3[3]
@@ -172,7 +178,7 @@ int pp_rgbnet_fwd(const float* params, const float* feat, const int32_t* count, 
                   float* rgb, void* stream);
 int pp_rgbnet_bwd(const float* params, const float* feat, const float* acts, const float* rgb,
                   const float* rgb_grad, const int32_t* count, int32_t capacity, float* scratch /*[2][cap][128] + 49152*/,
-                  float* params_grad /*atomic +=*/, float* feat_grad, void* stream);
+                  float* params_grad /*atomic +=*/, float* feat_grad, void* ctx /*pp_context or NULL*/, void* stream);
 
 /* warp MLP (DeformedImplicitField, lib/deformation/deform_net.py:12-31, modules.py:43-124): 3->128x4->4 ReLU,
  * evaluated together with its input Jacobian in forward mode (row 0 primal, rows 1-3 tangents), which
@@ -184,7 +190,8 @@ int pp_warp_fwd(const float* params, const float* pts, const int32_t* count, int
                 float* acts, float* out, void* stream);
 int pp_warp_bwd(const float* params, const float* pts, const float* acts, const float* out_grad,
                 const int32_t* count, int32_t capacity, float out_range, float* scratch /*[2][cap*4][128] + 49152*/,
-                float* params_grad /*atomic +=*/, float* pts_grad /* += */, void* stream);
+                float* params_grad /*atomic +=*/, float* pts_grad /* += */, void* ctx /*pp_context or NULL*/,
+                void* stream);
 
 /* ---------------------------------------------------------------- losses: lib/losses.py:6-74 (object_losses),
  * forward values + gradients w.r.t. the render outputs in one pass.  loss_scale multiplies every gradient
@@ -284,7 +291,8 @@ int pp_mlp_fwd(const float* params, const float* feat, int32_t in_ld, int32_t n_
                void* stream);
 int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld, int32_t n_gemm, const float* acts,
                const float* out, const float* out_grad, const int32_t* count, int32_t capacity, float* scratch,
-               float* params_grad, float* feat_grad, float* logit_add_grad, int32_t logit_add_ld, void* stream);
+               float* params_grad, float* feat_grad, float* logit_add_grad, int32_t logit_add_ld, void* ctx,
+               void* stream);
 /* cumprod_exclusive(clamp_min(1-alpha,1e-10)) compositing without early stop (dvgo_ori.py:478-489): weights[M], T[M],
  * alphainv_last[N], rgb_acc[N,3] = sum w*rgb (un-clamped, bg not added), cum_weights[N], depth_acc[N] = sum w*step_w.
  * The backward is pp_march_bwd. */

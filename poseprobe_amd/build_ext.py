@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libposeprobe_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-Wno-pass-failed',
-         '-Wno-unused-result']
+         '-Wno-unused-result', '-Wno-unused-value']
 
 
 def sources():

@@ -475,8 +475,67 @@ __global__ __launch_bounds__(256) void k_rgb_out_bwd(const float* __restrict__ W
 // weight-gradient GEMM: a FIXED number of work-groups splits the (device-side) row count evenly; measured optimum on
 // MI355X ~ 450 work-groups (more: the 64 KB of contended atomics per work-group dominates; fewer: idle CUs).
 static const int TN_WGS = 448;
+
+// ------------------------------------------------------------------------------------------------ side-stream context
+// The weight-gradient GEMM (k_gemm_tn) and the data-gradient GEMM of one layer both consume Ybar_k and are otherwise
+// independent; each keeps the matrix pipe only ~55 % busy on its own (K = 128 leaves a tile prologue / epilogue per
+// 128 MFMAs).  With a context the backward chains fork the weight-gradient GEMM onto an auxiliary HIP stream so the
+// two kernels co-reside on the CUs and fill each other's MFMA bubbles.  The context is explicit caller-owned state
+// (no globals); fork / join are event edges, so the sequence stays capturable in a hipGraph.
+struct PPContext {
+  hipStream_t aux;
+  hipEvent_t fork[16], join[16];
+};
+
+extern "C" int pp_context_create(void** ctx) {
+  PP_REQUIRE(ctx, "null pointer");
+  PPContext* c = new PPContext;
+  if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess) { delete c; pp_set_error("pp_context_create: stream"); return PP_ERR_LAUNCH; }
+  for (int i = 0; i < 16; ++i) {
+    hipEventCreateWithFlags(&c->fork[i], hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
+  }
+  *ctx = c;
+  return PP_OK;
+}
+
+extern "C" int pp_context_destroy(void* ctx) {
+  if (!ctx) return PP_OK;
+  PPContext* c = static_cast<PPContext*>(ctx);
+  hipStreamSynchronize(c->aux);
+  for (int i = 0; i < 16; ++i) { hipEventDestroy(c->fork[i]); hipEventDestroy(c->join[i]); }
+  hipStreamDestroy(c->aux);
+  delete c;
+  return PP_OK;
+}
+
+struct SideLane {
+  PPContext* c;
+  hipStream_t main;
+  int n = 0;        // forks issued
+  int waited = 0;   // joins already waited for
+  SideLane(void* ctx, hipStream_t m) : c(static_cast<PPContext*>(ctx)), main(m) {}
+  // stream on which the next side kernel must be launched (after everything enqueued on `main` so far)
+  hipStream_t fork() {
+    if (!c) return main;
+    hipEventRecord(c->fork[n], main);
+    hipStreamWaitEvent(c->aux, c->fork[n], 0);
+    return c->aux;
+  }
+  void forked() { if (c) { hipEventRecord(c->join[n], c->aux); ++n; } }
+  // main waits for every side kernel issued so far except the `keep` most recent ones
+  void join(int keep = 0) {
+    if (!c) return;
+    for (; waited < n - keep; ++waited) hipStreamWaitEvent(main, c->join[waited], 0);
+  }
+};
+
 static const int GEMM_MAX_WG = 256 * 5;     // 5 resident work-groups per CU at BM=64 (25 KB LDS, 90 regs)
-static inline int gemm_grid(int rows, int bm) { int t = pp_div_up(rows, bm); return t < GEMM_MAX_WG ? t : GEMM_MAX_WG; }
+static const int GEMM_MAX_WG_SHARED = 256 * 3;   // when a weight-gradient GEMM runs beside it (register file: 2 x 96 + 2 x 144)
+static inline int gemm_grid(int rows, int bm, bool shared = false) {
+  int t = pp_div_up(rows, bm), cap = shared ? GEMM_MAX_WG_SHARED : GEMM_MAX_WG;
+  return t < cap ? t : cap;
+}
 #ifndef PP_GEMM_BM
 #define PP_GEMM_BM 64
 #endif
@@ -511,35 +570,42 @@ extern "C" int pp_mlp_fwd(const float* params, const float* feat, int32_t in_ld,
 extern "C" int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld, int32_t n_gemm, const float* acts,
                           const float* out, const float* out_grad, const int32_t* count, int32_t capacity,
                           float* scratch, float* params_grad, float* feat_grad, float* logit_add_grad,
-                          int32_t logit_add_ld, void* stream) {
+                          int32_t logit_add_ld, void* ctx, void* stream) {
   PP_REQUIRE(params && feat && acts && out && out_grad && count && scratch && params_grad, "null pointer");
   PP_REQUIRE(capacity > 0 && in_ld % 32 == 0 && in_ld <= 128 && n_gemm >= 1 && n_gemm <= 8, "bad sizes");
   hipStream_t st = pp_stream(stream);
+  SideLane side(ctx, st);
   const size_t LS = (size_t)capacity * 128;
   float* cur = scratch;
   float* nxt = scratch + LS;
   float* wt = scratch + 2 * LS;      // one transposed weight matrix at a time (128*128 floats)
-  dim3 g(gemm_grid(capacity, PP_GEMM_BM)), gt(TN_WGS), b(256);
+  dim3 g(gemm_grid(capacity, PP_GEMM_BM, ctx != nullptr)), gt(TN_WGS), b(256);
   const size_t oo = mlp_off_out(in_ld, n_gemm);
   hipLaunchKernelGGL(k_rgb_out_bwd, dim3(pp_div_up(capacity, STRIP)), b, 0, st, params + oo, acts + (n_gemm - 1) * LS, out,
                      out_grad, count, capacity, cur, params_grad + oo, params_grad + oo + 3 * 128, logit_add_grad,
                      logit_add_ld);
   for (int l = n_gemm - 1; l >= 1; --l) {
     const size_t ow = mlp_off_hidden(in_ld, l);
-    hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + ow, wt, 128, 128);
-    hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, cur, acts + (l - 1) * LS, 128, 128, params_grad + ow, 128,
+    hipStream_t ss = side.fork();                      // weight gradient of layer l beside its data gradient
+    hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, ss, cur, acts + (l - 1) * LS, 128, 128, params_grad + ow, 128,
                        params_grad + ow + 128 * 128, count, 1, capacity);
+    side.forked();
+    side.join(1);                                      // the previous layer's side GEMM still reads `nxt`
+    hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + ow, wt, 128, 128);
     hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 1, PP_GEMM_BM>), g, b, 0, st, cur, 128, wt, 128, 128, 128, nullptr,
                        acts + (l - 1) * LS, 128, nxt, 128, count, 1, capacity);
     float* tmp = cur; cur = nxt; nxt = tmp;
   }
-  hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, st, cur, feat, in_ld, in_ld, params_grad, in_ld,
+  hipStream_t ss = side.fork();
+  hipLaunchKernelGGL((k_gemm_tn<1>), gt, b, 0, ss, cur, feat, in_ld, in_ld, params_grad, in_ld,
                      params_grad + (size_t)128 * in_ld, count, 1, capacity);
+  side.forked();
   if (feat_grad) {
     hipLaunchKernelGGL(k_transpose, dim3(pp_div_up(128 * in_ld, 256)), b, 0, st, params, wt, 128, in_ld);
     hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_PLAIN, 1, PP_GEMM_BM>), g, b, 0, st, cur, 128, wt, 128, 128, in_ld, nullptr,
                        nullptr, 0, feat_grad, in_ld, count, 1, capacity);
   }
+  side.join(0);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }
@@ -552,10 +618,10 @@ extern "C" int pp_rgbnet_fwd(const float* params, const float* feat, const int32
 
 extern "C" int pp_rgbnet_bwd(const float* params, const float* feat, const float* acts, const float* rgb,
                              const float* rgb_grad, const int32_t* count, int32_t capacity, float* scratch,
-                             float* params_grad, float* feat_grad, void* stream) {
+                             float* params_grad, float* feat_grad, void* ctx, void* stream) {
   PP_REQUIRE(feat_grad, "null pointer");
   return pp_mlp_bwd(params, feat, 64, 3, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad, nullptr, 0,
-                    stream);
+                    ctx, stream);
 }
 
 extern "C" int pp_warp_fwd(const float* params, const float* pts, const int32_t* count, int32_t capacity,
@@ -582,41 +648,40 @@ extern "C" int pp_warp_fwd(const float* params, const float* pts, const int32_t*
 
 extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* acts, const float* out_grad,
                            const int32_t* count, int32_t capacity, float out_range, float* scratch,
-                           float* params_grad, float* pts_grad, void* stream) {
+                           float* params_grad, float* pts_grad, void* ctx, void* stream) {
   PP_REQUIRE(params && pts && acts && out_grad && count && scratch && params_grad && pts_grad, "null pointer");
   PP_REQUIRE(capacity > 0, "capacity<=0");
   hipStream_t st = pp_stream(stream);
+  SideLane side(ctx, st);
   const int rcap = capacity * 4;
   const size_t LS = (size_t)rcap * 128;
-  float* s0 = scratch;
-  float* s1 = scratch + LS;
-  dim3 g(gemm_grid(rcap, PP_GEMM_BM)), gt(TN_WGS), b(256);
-  hipLaunchKernelGGL(k_warp_l4_bwd, dim3(pp_div_up(capacity, STRIP)), b, 0, st, params + WP_W4, acts + 3 * LS, out_grad,
-                     count, capacity, out_range, s0, params_grad + WP_W4, params_grad + WP_B4);
+  float* cur = scratch;
+  float* nxt = scratch + LS;
   float* wt = scratch + 2 * LS;          // transposed weights W3^T, W2^T, W1^T
+  dim3 g(gemm_grid(rcap, PP_GEMM_BM, ctx != nullptr)), gt(TN_WGS), b(256);
   hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + WP_W3, wt, 128, 128);
   hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + WP_W2, wt + 16384, 128, 128);
   hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + WP_W1, wt + 32768, 128, 128);
-  // layer 3
-  hipLaunchKernelGGL((k_gemm_tn<4>), gt, b, 0, st, s0, acts + 2 * LS, 128, 128, params_grad + WP_W3, 128,
-                     params_grad + WP_B3, count, 4, rcap);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 4, PP_GEMM_BM>), g, b, 0, st, s0, 128, wt, 128, 128, 128, nullptr,
-                     acts + 2 * LS, 128, s1, 128, count, 4, rcap);
-  // layer 2
-  hipLaunchKernelGGL((k_gemm_tn<4>), gt, b, 0, st, s1, acts + LS, 128, 128, params_grad + WP_W2, 128,
-                     params_grad + WP_B2, count, 4, rcap);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 4, PP_GEMM_BM>), g, b, 0, st, s1, 128, wt + 16384, 128, 128, 128, nullptr,
-                     acts + LS, 128, s0, 128, count, 4, rcap);
-  // layer 1
-  hipLaunchKernelGGL((k_gemm_tn<4>), gt, b, 0, st, s0, acts, 128, 128, params_grad + WP_W1, 128, params_grad + WP_B1,
-                     count, 4, rcap);
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 4, PP_GEMM_BM>), g, b, 0, st, s0, 128, wt + 32768, 128, 128, 128, nullptr,
-                     acts, 128, s1, 128, count, 4, rcap);
-  // layer 0
-  hipLaunchKernelGGL(k_warp_l0_bwd_pts, dim3(pp_div_up(capacity * 16, 256)), b, 0, st, params + WP_W0, s1, count, capacity,
+  hipLaunchKernelGGL(k_warp_l4_bwd, dim3(pp_div_up(capacity, STRIP)), b, 0, st, params + WP_W4, acts + 3 * LS, out_grad,
+                     count, capacity, out_range, cur, params_grad + WP_W4, params_grad + WP_B4);
+  const int w_off[4] = {0, WP_W1, WP_W2, WP_W3};
+  const int b_off[4] = {0, WP_B1, WP_B2, WP_B3};
+  for (int l = 3; l >= 1; --l) {
+    hipStream_t ss = side.fork();                      // weight gradient of layer l beside its data gradient
+    hipLaunchKernelGGL((k_gemm_tn<4>), gt, b, 0, ss, cur, acts + (l - 1) * LS, 128, 128, params_grad + w_off[l], 128,
+                       params_grad + b_off[l], count, 4, rcap);
+    side.forked();
+    side.join(1);                                      // the previous layer's side GEMM still reads `nxt`
+    hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_MASK, 4, PP_GEMM_BM>), g, b, 0, st, cur, 128, wt + (3 - l) * 16384, 128, 128,
+                       128, nullptr, acts + (l - 1) * LS, 128, nxt, 128, count, 4, rcap);
+    float* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  // layer 0 (cur = Ybar1)
+  hipLaunchKernelGGL(k_warp_l0_bwd_pts, dim3(pp_div_up(capacity * 16, 256)), b, 0, st, params + WP_W0, cur, count, capacity,
                      pts_grad);
-  hipLaunchKernelGGL(k_warp_l0_bwd_w, dim3(pp_div_up(capacity, STRIP0)), b, 0, st, pts, s1, count, capacity,
+  hipLaunchKernelGGL(k_warp_l0_bwd_w, dim3(pp_div_up(capacity, STRIP0)), b, 0, st, pts, cur, count, capacity,
                      params_grad + WP_W0, params_grad + WP_B0);
+  side.join(0);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }

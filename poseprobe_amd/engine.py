@@ -195,8 +195,13 @@ class RenderCore:
     """Forward and backward kernel chains over a Workspace.  Parameters are passed as raw device tensors:
     k0_cl [X,Y,Z,C] (channels-last), sdf [X,Y,Z], flat (FlatParams-like with .view)."""
 
-    def __init__(self, cfg: SceneConfig):
+    def __init__(self, cfg: SceneConfig, use_side_stream=False):
         self.cfg = cfg
+        import os
+        # Forking the weight-gradient GEMMs onto an auxiliary stream (pp_context) is implemented but OFF by default:
+        # measured on MI355X it is 4-5 % slower than the sequential chain (both GEMMs are matrix-pipe bound and the
+        # persistent data-gradient GEMM has to give up residency).  PP_SIDE_STREAM=1 turns it on for experiments.
+        self.use_side_stream = use_side_stream or os.environ.get('PP_SIDE_STREAM') == '1'
 
     # -- forward -------------------------------------------------------------------------------------------
     def sample(self, ws, jitter):
@@ -229,8 +234,9 @@ class RenderCore:
             ws.g_alpha.add_(g_alpha_ext)
         if g_rgb_ext is not None:
             ws.g_rgb.add_(g_rgb_ext)
+        ctx = ops.side_context() if self.use_side_stream else None
         ops.rgbnet_bwd(rgbnet_p, ws.feat, ws.rgb_acts, ws.rgb, ws.g_rgb, ws.count, ws.cap, ws.scratch[-(2 * ws.cap * 128 + 49152):],
-                       rgbnet_grad, ws.g_feat)
+                       rgbnet_grad, ws.g_feat, ctx)
         ops.color_feat_bwd(sc, k0_cl, ws.pts, ws.viewdirs, ws.ray_id, ws.gradient, pe_w, ws.count, ws.cap, ws.g_feat,
                            k0_grad_cl, ws.g_pts, ws.g_gradient, ws.g_view_s)
         if after_k0_grad is not None:
@@ -241,7 +247,7 @@ class RenderCore:
                          ws.g_alpha, ws.g_gradient, None, g_sdf_deform, g_grad_deform, g_correction, 1, ws.g_warp_out,
                          ws.g_pts, ws.g_view_s, sdf_ab_grad)
         ops.warp_bwd(warp_p, ws.pts, ws.warp_acts, ws.g_warp_out, ws.count, ws.cap, cfg.out_range, ws.scratch, warp_grad,
-                     ws.g_pts)
+                     ws.g_pts, ctx)
 
 
 class TrainEngine:

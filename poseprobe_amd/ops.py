@@ -160,18 +160,31 @@ def rgbnet_fwd(params, feat, count, capacity, acts, rgb):
     _lib.call('pp_rgbnet_fwd', _f(params), _f(feat), _i(count), capacity, _f(acts), _f(rgb), _stream())
 
 
-def rgbnet_bwd(params, feat, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad):
+_CTX = {}
+
+
+def side_context():
+    """Caller-owned pp_context for the current device (auxiliary stream for the weight-gradient GEMMs)."""
+    dev = torch.cuda.current_device()
+    if dev not in _CTX:
+        h = ctypes.c_void_p()
+        _lib.call('pp_context_create', ctypes.byref(h))
+        _CTX[dev] = h
+    return _CTX[dev]
+
+
+def rgbnet_bwd(params, feat, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad, ctx=None):
     _lib.call('pp_rgbnet_bwd', _f(params), _f(feat), _f(acts), _f(rgb), _f(rgb_grad), _i(count), capacity,
-              _f(scratch), _f(params_grad), _f(feat_grad), _stream())
+              _f(scratch), _f(params_grad), _f(feat_grad), ctx, _stream())
 
 
 def warp_fwd(params, pts, count, capacity, out_range, acts, out):
     _lib.call('pp_warp_fwd', _f(params), _f(pts), _i(count), capacity, float(out_range), _f(acts), _f(out), _stream())
 
 
-def warp_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad):
+def warp_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad, ctx=None):
     _lib.call('pp_warp_bwd', _f(params), _f(pts), _f(acts), _f(out_grad), _i(count), capacity, float(out_range),
-              _f(scratch), _f(params_grad), _f(pts_grad), _stream())
+              _f(scratch), _f(params_grad), _f(pts_grad), ctx, _stream())
 
 
 # ------------------------------------------------------------------------------------------- losses / optimiser
@@ -242,9 +255,10 @@ def mlp_fwd(params, feat, in_ld, n_gemm, count, capacity, logit_add, logit_add_l
 
 
 def mlp_bwd(params, feat, in_ld, n_gemm, acts, out, out_grad, count, capacity, scratch, params_grad, feat_grad,
-            logit_add_grad, logit_add_ld):
+            logit_add_grad, logit_add_ld, ctx=None):
     _lib.call('pp_mlp_bwd', _f(params), _f(feat), int(in_ld), int(n_gemm), _f(acts), _f(out), _f(out_grad), _i(count),
-              capacity, _f(scratch), _f(params_grad), _f(feat_grad), _f(logit_add_grad), int(logit_add_ld), _stream())
+              capacity, _f(scratch), _f(params_grad), _f(feat_grad), _f(logit_add_grad), int(logit_add_ld), ctx,
+              _stream())
 
 
 def march_dvgo_fwd(alpha, rgb, step_w, ray_start, n_rays, weights, T, alphainv_last, i_end, rgb_acc, cum_weights, depth_acc):
