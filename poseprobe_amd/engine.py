@@ -103,9 +103,8 @@ class Workspace:
         self.alphainv_last, self.i_end = e(N, **f), e(N, **i)
         self.rgb_marched, self.rgb_pre = e(N, 3, **f), e(N, 3, **f)
         self.cum_weights, self.depth_acc = e(N, **f), e(N, **f)
-        self.mask_sum = torch.zeros(1, **f)
-        self.loss_out = torch.zeros(8, **f)
-        self.tv_out = torch.zeros(1, **f)
+        self.zero_block = torch.zeros(16, **f)          # loss_out[8] | tv_out[1] | mask_sum[1] : one memset per step
+        self.loss_out, self.tv_out, self.mask_sum = self.zero_block[:8], self.zero_block[8:9], self.zero_block[9:10]
         if not backward:
             return
         # backward buffers
@@ -292,10 +291,20 @@ class TrainEngine:
         self.dist = dist_ctx
         segs = [self.flat.off[n][0] + _pad(self.flat.off[n][1]) for n, _ in FlatParams.SEG]
         self.seg_end = torch.tensor(segs, dtype=torch.int32, device=self.dev)
-        self.seg_lr = torch.zeros(len(segs), **f)
         self.pose_seg_end = torch.tensor([n_views * 6], dtype=torch.int32, device=self.dev)
-        self.pose_seg_lr = torch.zeros(1, **f)
-        self.pe_w = torch.zeros(cfg.posbase_pe + cfg.viewbase_pe, **f)
+        # per-step scalars travel in ONE async H2D copy from a pinned staging buffer:
+        #   [0:npe) BARF weights | [npe:npe+3) lr of sdf_ab, rgbnet, warp | [npe+3] pose lr
+        self.npe = cfg.posbase_pe + cfg.viewbase_pe
+        # ring of pinned slots: the host may run many steps ahead of the GPU (no sync in the step), a slot must not be
+        # rewritten before its async copy has executed; the launch queue never holds 256 steps
+        self.step_host = torch.zeros(256, self.npe + 4, dtype=torch.float32)
+        if self.dev.type == 'cuda':
+            self.step_host = self.step_host.pin_memory()
+        self._slot = 0
+        self.step_dev = torch.zeros(self.npe + 4, **f)
+        self.pe_w = self.step_dev[:self.npe]
+        self.seg_lr = self.step_dev[self.npe:self.npe + 3]
+        self.pose_seg_lr = self.step_dev[self.npe + 3:self.npe + 4]
 
     # ---- data / parameter loading ---------------------------------------------------------------------------
     def set_views(self, images, masks, Ks, w2c_init):
@@ -340,13 +349,13 @@ class TrainEngine:
                               ws.rays_o, ws.rays_d, ws.viewdirs, ws.target, ws.mask_px)
         self.core.sample(ws, jitter)
         progress = global_step / cfg.N_iters
-        self.pe_w.copy_(torch.from_numpy(cfg.pe_weights(progress)), non_blocking=True)
+        self._upload_step_scalars(progress)
         s_val = cfg.s_val(global_step)
         inv_s = float(np.float32(1.0) / np.float32(s_val))
         P = self.flat
         self.core.forward(ws, self.k0_cl, self.sdf, P.view('sdf_ab'), P.view('rgbnet'), P.view('warp'), inv_s, self.pe_w,
                           before_k0_use=None if self.dist is None else (lambda: self.dist.wait_parameters(self)))
-        ws.loss_out.zero_()
+        ws.zero_block.zero_()
         w_dyn = dynamic_weight(1e-1, 1e-3, global_step, cfg.N_iters)
         ls = self.loss_scale
         ops.loss_rays(ws.rgb_marched, ws.alphainv_last, ws.cum_weights, ws.target, ws.mask_px, ws.mask_sum, self.w_main,
@@ -367,6 +376,17 @@ class TrainEngine:
         ops.pose_bwd(self.jac, self.c2w_grad, self.se3_grad)
         return s_val, w_dyn
 
+    def _upload_step_scalars(self, progress):
+        """BARF weights for this step and the learning rates the optimiser will use at the END of this step (the
+        per-step exponential decay precedes the optimiser step, recon_scene.py:742-768)."""
+        h = self.step_host[self._slot]
+        self._slot = (self._slot + 1) % self.step_host.shape[0]
+        h[:self.npe] = torch.from_numpy(self.cfg.pe_weights(progress))
+        d = self.decay
+        h[self.npe + 0], h[self.npe + 1], h[self.npe + 2] = self.lr['sdf_ab'] * d, self.lr['rgbnet'] * d, self.lr['warp'] * d
+        h[self.npe + 3] = self.lr_pose
+        self.step_dev.copy_(h, non_blocking=True)
+
     def optimizer_step(self, optimize_pose=True, grad_scale=1.0):
         cfg = self.cfg
         self.n_step += 1
@@ -375,16 +395,13 @@ class TrainEngine:
         X, Y, Z = cfg.world_size
         tv_scale = self.loss_scale * self.w_tv / (3.0 * X * Y * Z * cfg.k0_dim)
         src, dst = self.k0[self.k0_cur], self.k0[1 - self.k0_cur]
-        self.ws.tv_out.zero_()
         xb, xe = self.x_slab
         ops.grid_tv_adam_step(src, dst, self.k0_grad, self.k0_m, self.k0_v, cfg.world_size, cfg.k0_dim, xb, xe, tv_scale,
                               grad_scale, self.lr['k0'], 0.9, 0.99, 1e-8, self.n_step, self.ws.tv_out)
         self.k0_cur = 1 - self.k0_cur
-        self.seg_lr.copy_(torch.tensor([self.lr['sdf_ab'], self.lr['rgbnet'], self.lr['warp']]), non_blocking=True)
         ops.adam_flat(self.flat.data, self.flat.grad, self.flat.m, self.flat.v, self.seg_end, self.seg_lr, grad_scale, 0.9,
                       0.99, 1e-8, self.n_step, 1)
         if optimize_pose:
-            self.pose_seg_lr.fill_(self.lr_pose)
             ops.adam_flat(self.se3.view(-1), self.se3_grad.view(-1), self.se3_m.view(-1), self.se3_v.view(-1),
                           self.pose_seg_end, self.pose_seg_lr, grad_scale, 0.9, 0.999, 1e-8, self.n_step, 1)
             self.lr_pose *= self.pose_gamma
