@@ -1,0 +1,155 @@
+"""GPU checks at BASELINE.json's full size (160^3 grid, 3x400x400 views, 1024 rays, 186 samples/ray) through
+size-independent properties of the domain - the oracle takes ~5 s per step here, so instead of value parity:
+sortedness / consistency of the ray-major compaction, the transmittance identity sum(w) + T_last = 1, ranges,
+run-to-run determinism of everything that is not an atomic sum, a finite-difference check of the pose gradient and
+the Adam / TV optimiser identities."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def engine():
+    from poseprobe_amd import synthetic as syn
+    from poseprobe_amd.engine import SceneConfig, TrainEngine
+    from poseprobe_amd.params_init import reference_like_params
+    G, H, W, V, N = 160, 400, 400, 3, 1024
+    cfg = SceneConfig(syn.XYZ_MIN, syn.XYZ_MAX, G ** 3, out_range=float(syn.range_shape().max()))
+    views = syn.make_views(V, H, W)
+    eng = TrainEngine(cfg, V, H, W, N, pose_iters=3000)
+    eng.set_views(views['images'], views['masks'], views['Ks'], views['w2c'])
+    P = reference_like_params(cfg, 3)
+    eng.load_reference_params(P['k0'], P['sdf'], P['sdf_alpha'], P['sdf_beta'], P['rgbnet'], P['warp'],
+                              se3=torch.tensor(syn.se3_perturbation(V)))
+    idx, jit = syn.step_randomness(V * H * W, N, seed=5)
+    return eng, cfg, torch.tensor(idx, dtype=torch.int32, device='cuda'), torch.tensor(jit, device='cuda')
+
+
+def total_loss(eng, gs):
+    from poseprobe_amd.engine import dynamic_weight
+    L = eng.losses()
+    w = dynamic_weight(1e-1, 1e-3, gs, eng.cfg.N_iters)
+    return (L['img_render'] + 0.01 * L['weight_entropy_last'] + L['grad_constraint'] + 0.1 * L['mask_render']
+            + w * (L['grad_deform_constraint'] + L['sdf_correct_constraint'] + L['sdf_deform_constraint']))
+
+
+def test_compaction_scan_and_ranges(engine):
+    eng, cfg, idx, jit = engine
+    eng.zero_grads()
+    eng.render_and_grads(idx, jit, 10)
+    torch.cuda.synchronize()
+    ws = eng.ws
+    M = int(ws.count.item())
+    assert cfg.n_samples == 186 and 30000 < M < 100000
+    rid, sk, rs = ws.ray_id[:M].cpu().numpy(), ws.step_k[:M].cpu().numpy(), ws.ray_start.cpu().numpy()
+    assert (np.diff(rid) >= 0).all()                                          # ray-major order
+    assert rs[0] == 0 and rs[-1] == M and (np.diff(rs) >= 0).all()
+    assert np.array_equal(np.bincount(rid, minlength=ws.N), np.diff(rs))      # prefix == per-ray counts
+    same = rid[1:] == rid[:-1]
+    assert (sk[1:][same] > sk[:-1][same]).all() and sk.max() < cfg.n_samples  # strictly increasing steps inside a ray
+    pts = ws.pts[:M].cpu().numpy()
+    assert (pts >= np.asarray(cfg.xyz_min) - 1e-6).all() and (pts <= np.asarray(cfg.xyz_max) + 1e-6).all()
+    a, w, T = ws.alpha[:M].cpu().numpy(), ws.weights[:M].cpu().numpy(), ws.T[:M].cpu().numpy()
+    assert (a >= 0).all() and (a <= 1).all() and (w >= 0).all()
+    ie = ws.i_end.cpu().numpy()
+    live = np.zeros(M, bool)
+    for r in np.nonzero(np.diff(rs))[0][:200]:
+        live[rs[r]:ie[r]] = True
+        # transmittance identity on rays (exact in real arithmetic, fp32 rounding here): sum w + T_last = 1
+        assert abs(w[rs[r]:rs[r + 1]].sum() + float(ws.alphainv_last[r]) - 1.0) < 2e-5
+    np.testing.assert_allclose(w[live], (T * a)[live], rtol=1e-6, atol=1e-9)
+    rgbm = ws.rgb_marched.cpu().numpy()
+    assert (rgbm >= 0).all() and (rgbm <= 1).all() and np.isfinite(rgbm).all()
+    for t in (eng.k0_grad, eng.flat.grad, eng.se3_grad):
+        assert torch.isfinite(t).all()
+    assert float(eng.se3_grad[0].abs().sum()) == 0.0                           # view 0 is never refined (PnP mode)
+
+
+def test_forward_is_deterministic(engine):
+    eng, cfg, idx, jit = engine
+    eng.zero_grads()
+    eng.render_and_grads(idx, jit, 10)
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in (eng.ws.rgb_marched, eng.ws.alphainv_last, eng.ws.weights, eng.ws.gradient)]
+    eng.zero_grads()
+    eng.render_and_grads(idx, jit, 10)
+    torch.cuda.synchronize()
+    for a, b in zip(ref, (eng.ws.rgb_marched, eng.ws.alphainv_last, eng.ws.weights, eng.ws.gradient)):
+        assert torch.equal(a, b)                                               # forward has no atomics: bit-identical
+
+
+def test_full_size_step_against_the_oracle(engine):
+    """One full-size step against the oracle (torch-CPU, ~5-10 s on the box's host cores): pixels, losses and the
+    gradients of the pose, of alpha/beta and of the MLPs.  (A finite-difference check is not meaningful here: the
+    trilinear normal is piecewise constant, so the loss has O(1) jumps that autograd - and the reference - ignore.)"""
+    from oracle import voxurf_oracle as O
+    from poseprobe_amd import synthetic as syn
+    from poseprobe_amd.params_init import reference_like_params
+    from tests.helpers import assert_close
+    eng, cfg, idx, jit = engine
+    eng.zero_grads()
+    eng.render_and_grads(idx, jit, 10)
+    torch.cuda.synchronize()
+    V, H, W = 3, 400, 400
+    views = syn.make_views(V, H, W)
+    rs = syn.range_shape()
+    scene = O.Scene(syn.XYZ_MIN, syn.XYZ_MAX, 160 ** 3, output_range=float(rs.max()), rect_size=rs.tolist())
+    P = O.params_require_grad(reference_like_params(cfg, 3))
+    se3 = torch.tensor(syn.se3_perturbation(V), requires_grad=True)
+    c2w = O.pose_invert(O.current_pose_pnp(se3, torch.tensor(views['w2c'])))
+    ro, rd, vd, target, mask = O.select_training_rays(idx.cpu().long(), torch.tensor(views['images']),
+                                                      torch.tensor(views['masks']), torch.tensor(views['Ks']), c2w)
+    out = O.voxurf_forward(P, scene, ro, rd, vd, jitter=jit.cpu(), global_step=10)
+    S, Wt, loss = O.object_losses(out, target, mask, 10, scene.N_iters)
+    (loss * 0.1).backward()
+    c = lambda t: t.detach().cpu().numpy()
+    M = int(eng.ws.count.item())
+    assert M == out['weights'].shape[0]
+    assert np.array_equal(c(eng.ws.ray_id[:M]), c(out['_ray_id']))
+    assert_close(c(eng.ws.rgb_marched), c(out['rgb_marched']), rtol=1e-4, atol=1e-5, name='rgb_marched')
+    assert_close(c(eng.ws.alphainv_last), c(out['alphainv_cum']), rtol=1e-4, atol=1e-5, name='alphainv_cum')
+    L = eng.losses()
+    for k in ('img_render', 'weight_entropy_last', 'grad_constraint', 'grad_deform_constraint', 'sdf_deform_constraint',
+              'mask_render'):
+        assert_close(np.float32(L[k]), c(S[k]), rtol=2e-4, atol=1e-7, name='loss.' + k)
+    tol = dict(rtol=1e-3, scaled=5e-5)
+    assert_close(c(eng.se3_grad), c(se3.grad), atol=1e-6, name='g.se3', **tol)
+    g = eng.flat.export_grads()
+    assert_close(c(g['sdf_alpha']), c(P['sdf_alpha'].grad), atol=1e-7, name='g.sdf_alpha', **tol)
+    assert_close(c(g['sdf_beta']), c(P['sdf_beta'].grad), atol=1e-7, name='g.sdf_beta', **tol)
+    for li in (0, 3):
+        assert_close(c(g['rgbnet'][li][0]), c(P['rgbnet'][li][0].grad), atol=1e-8, name=f'g.rgbnet{li}.W', **tol)
+    for li in (0, 2, 4):
+        assert_close(c(g['warp'][li][0]), c(P['warp'][li][0].grad), atol=2e-7, name=f'g.warp{li}.W', **tol)
+
+
+def test_optimizer_identities_at_full_grid(engine):
+    """Zero render gradient, zero moments, tv weight 0  =>  the fused pass leaves the parameters bit-identical and
+    zero-fills the gradient; its TV value equals the standalone TV kernel's."""
+    from poseprobe_amd import ops
+    eng, cfg, idx, jit = engine
+    X, Y, Z = cfg.world_size
+    p_in = eng.k0_cl
+    p_out = torch.empty_like(p_in)
+    grad = torch.zeros_like(p_in)
+    m, v = torch.zeros_like(p_in), torch.zeros_like(p_in)
+    tv1, tv2 = torch.zeros(1, device='cuda'), torch.zeros(1, device='cuda')
+    ops.grid_tv_adam_step(p_in, p_out, grad, m, v, (X, Y, Z), cfg.k0_dim, 0, X, 0.0, 1.0, 0.1, 0.9, 0.99, 1e-8, 1, tv1)
+    assert torch.equal(p_in, p_out) and float(m.abs().max()) == 0 and float(v.abs().max()) == 0
+    ops.grid_tv_value(p_in, (X, Y, Z), cfg.k0_dim, tv2)
+    assert abs(float(tv1) - float(tv2)) <= 1e-4 * float(tv2)
+    # linearity of the TV gradient in its scale; sharded slabs compose to the full pass
+    g1, g2 = torch.zeros_like(p_in), torch.zeros_like(p_in)
+    one = torch.ones(1, device='cuda')
+    ops.grid_tv_grad(p_in, (X, Y, Z), cfg.k0_dim, 1.0, one, g1)
+    ops.grid_tv_grad(p_in, (X, Y, Z), cfg.k0_dim, 0.5, one, g2)
+    assert torch.equal(g1, 2 * g2)
+    pa, pb = torch.empty_like(p_in), torch.empty_like(p_in)
+    ga, gb = g1.clone(), g1.clone()
+    ma, va, mb, vb = (torch.zeros_like(p_in) for _ in range(4))
+    ops.grid_tv_adam_step(p_in, pa, ga, ma, va, (X, Y, Z), cfg.k0_dim, 0, X, 1e-6, 1.0, 0.1, 0.9, 0.99, 1e-8, 3, None)
+    for xb, xe in ((0, 20), (20, 100), (100, X)):
+        ops.grid_tv_adam_step(p_in, pb, gb, mb, vb, (X, Y, Z), cfg.k0_dim, xb, xe, 1e-6, 1.0, 0.1, 0.9, 0.99, 1e-8, 3, None)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
