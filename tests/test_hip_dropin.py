@@ -204,3 +204,57 @@ def test_directvoxgo_twin_matches_reference():
     for li, lin in enumerate([m.rgbnet[0], m.rgbnet[2][0], m.rgbnet[3]]):
         assert_close(c(lin.weight.grad), d[f'grad.rgbnet.{li}.weight'], atol=1e-9, name=f'g.rgbnet{li}.W', **tol)
         assert_close(c(lin.bias.grad), d[f'grad.rgbnet.{li}.bias'], atol=1e-9, name=f'g.rgbnet{li}.b', **tol)
+
+
+def test_reference_style_training_loop_with_hip_adam(tmp_path):
+    """create_optimizer_or_freeze_model + Adam.step (lib/utils.py) driving the drop-in Voxurf for 2 steps, checked
+    against the oracle trainer; then a checkpoint round trip through load_model."""
+    from oracle import voxurf_oracle as O
+    from poseprobe_amd import camera, synthetic as syn, utils
+    from poseprobe_amd import voxurf_coarse as Model
+    from poseprobe_amd.config import ConfigDict
+    from poseprobe_amd.losses import object_losses
+    from tests.helpers import params_from_npz, scene_for
+    d = load('forward_g8_s10.npz')
+    m = make_model(d)
+    pm = Model.pose_model(i_train=np.arange(3), camera_noise=0.).cuda()
+    pm.se3_refine.data.copy_(torch.tensor(d['se3']))
+    cfg_train = ConfigDict(lrate_decay=10, lrate_k0=1e-1, lrate_rgbnet=1e-3, lrate_warp_network=1e-3, lrate_sdf_alpha=1e-2,
+                           lrate_sdf_beta=1e-2, lrate_sdf=0, weight_main=1., weight_tv_k0=.01, weight_mask=.1, lr_pose=1e-3,
+                           lr_pose_end=1e-4, sched_pose='ExponentialLR')
+    opt = utils.create_optimizer_or_freeze_model(m, cfg_train, global_step=0)
+    assert sorted(g['name'] for g in opt.param_groups) == ['k0', 'rgbnet', 'sdf_alpha', 'sdf_beta', 'warp_network']
+    opt_pose, sched = utils.create_optimizer_pose(pm, cfg_train, max_iter=1000)
+    P = params_from_npz(d)
+    st = O.TrainState(P, scene_for(d['G']), torch.tensor(d['w2c_init']), torch.tensor(d['Ks']), torch.tensor(d['images']),
+                      torch.tensor(d['masks']), se3_refine=torch.tensor(d['se3']), pose_iters=1000)
+    H, W = int(d['H']), int(d['W'])
+    imgs, msks = torch.tensor(d['images']).cuda(), torch.tensor(d['masks']).cuda()
+    decay = 0.1 ** (1 / 10000)
+    for s in range(2):
+        idx, jit = syn.step_randomness(3 * H * W, int(d['n_rand']), seed=60 + s)
+        st.step(torch.tensor(idx), torch.tensor(jit), 10 + s)
+        opt.zero_grad(set_to_none=True)
+        opt_pose.zero_grad()
+        w2c, c2w = camera.current_pose_c2w(pm.se3_refine, torch.tensor(d['w2c_init']).cuda())
+        target, mask, ro, rd, vd = Model.select_training_rays(torch.tensor(idx), imgs, msks, c2w, np.array([[H, W]] * 3), d['Ks'])
+        out = m(ro, rd, vd, use_deform=True, global_step=10 + s, near=0.24, far=4.8, bg=0, stepsize=1.5, inverse_y=True,
+                flip_x=False, flip_y=False, jitter=torch.tensor(jit))
+        loss = object_losses(out, cfg_train, target, mask, 10 + s, 10000, True)[2]
+        (loss * 0.1).backward()
+        for g in opt.param_groups:
+            g['lr'] = g['lr'] * decay
+        opt.step()
+        opt_pose.step()
+        sched.step()
+    c = lambda t: t.detach().cpu().numpy()
+    dev = np.abs(c(m.k0.grid) - c(P['k0']))
+    assert dev.max() < 0.02 and (dev > 1e-4).mean() < 0.02
+    assert_close(c(pm.se3_refine), c(st.se3), rtol=0, atol=2e-4, name='se3 after 2 steps')
+    assert_close(c(m.sdf_alpha), c(P['sdf_alpha']), rtol=0, atol=2e-4, name='sdf_alpha')
+    path = str(tmp_path / 'last_ckpt.tar')
+    torch.save({'global_step': 2, 'model_kwargs': m.get_kwargs(), 'MaskCache_kwargs': m.get_MaskCache_kwargs(),
+                'model_state_dict': m.state_dict(), 'optimizer_state_dict': opt.state_dict()}, path)
+    m2 = utils.load_model(Model.Voxurf, path)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a.cpu(), b.cpu()), k

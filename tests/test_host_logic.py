@@ -1,0 +1,63 @@
+"""CPU tests of host-side logic mirrored from the reference: config loader (`_base_` inheritance), parameter packing,
+BARF weights, s_val / dynamic-weight schedules, slab bounds."""
+import math
+import os
+
+import numpy as np
+import torch
+
+
+def test_config_base_inheritance(tmp_path):
+    from poseprobe_amd.config import Config
+    (tmp_path / 'default.py').write_text(
+        "expname = None\nfine_train = dict(N_iters=20000, N_rand=1024, lrate_k0=1e-1, ray_sampler='flatten')\n"
+        "fine_model_and_render = dict(num_voxels=160**3, stepsize=1.5)\ndata = dict(inverse_y=False, ndc=False)\n")
+    (tmp_path / 'scan1.py').write_text(
+        "_base_ = './default.py'\nexpname = 'scan1'\nsurf_train = dict(N_iters=10000, lr_pose=0.)\n"
+        "fine_train = dict(N_iters=10000)\nfine_model_and_render = dict(num_voxels=96**3)\ndata = dict(inverse_y=True)\n")
+    cfg = Config.fromfile(str(tmp_path / 'scan1.py'))
+    assert cfg.expname == 'scan1'
+    assert cfg.fine_train.N_iters == 10000 and cfg.fine_train.N_rand == 1024 and cfg.fine_train.ray_sampler == 'flatten'
+    assert cfg.fine_model_and_render.num_voxels == 96 ** 3 and cfg.fine_model_and_render.stepsize == 1.5
+    assert cfg.data.inverse_y is True and cfg.data.ndc is False
+    assert getattr(cfg.data, 'flip_x', 'dflt') == 'dflt'
+    assert 'lrate_k0' in cfg.fine_train.keys()
+
+
+def test_parameter_packing_roundtrip():
+    from poseprobe_amd.engine import pack_rgbnet, pack_warp, unpack_rgbnet, unpack_warp
+    from poseprobe_amd.ops import RGBNET_PARAMS, WARP_PARAMS
+    g = torch.Generator().manual_seed(0)
+    rg = [(torch.randn(128, 57, generator=g), torch.randn(128, generator=g)), (torch.randn(128, 128, generator=g), torch.randn(128, generator=g)),
+          (torch.randn(128, 128, generator=g), torch.randn(128, generator=g)), (torch.randn(3, 128, generator=g), torch.randn(3, generator=g))]
+    flat = pack_rgbnet(rg)
+    assert flat.numel() == RGBNET_PARAMS
+    for (W, b), (W2, b2) in zip(rg, unpack_rgbnet(flat)):
+        assert torch.equal(W, W2) and torch.equal(b, b2)
+    assert float(flat[:128 * 64].reshape(128, 64)[:, 57:].abs().sum()) == 0      # zero padding 57 -> 64
+    wp = [(torch.randn(128, 3, generator=g), torch.randn(128, generator=g))] + \
+         [(torch.randn(128, 128, generator=g), torch.randn(128, generator=g)) for _ in range(3)] + \
+         [(torch.randn(4, 128, generator=g), torch.randn(4, generator=g))]
+    flat = pack_warp(wp)
+    assert flat.numel() == WARP_PARAMS
+    for (W, b), (W2, b2) in zip(wp, unpack_warp(flat)):
+        assert torch.equal(W, W2) and torch.equal(b, b2)
+
+
+def test_schedules_match_the_oracle():
+    from oracle import voxurf_oracle as O
+    from poseprobe_amd import synthetic as syn
+    from poseprobe_amd.engine import SceneConfig, dynamic_weight
+    cfg = SceneConfig(syn.XYZ_MIN, syn.XYZ_MAX, 96 ** 3)
+    scene = O.Scene(syn.XYZ_MIN, syn.XYZ_MAX, 96 ** 3)
+    assert cfg.world_size == scene.world_size.tolist() == [96, 96, 96]
+    assert cfg.n_samples == scene.n_samples() == 113
+    assert np.float32(cfg.voxel_size) == np.float32(float(scene.voxel_size))
+    for prog in (0.0, 0.001, 0.6, 0.7, 0.8, 1.0):
+        w = cfg.pe_weights(prog)
+        assert np.array_equal(w[:5], O.barf_weights(scene, prog, 5).numpy())
+        assert np.array_equal(w[5:], O.barf_weights(scene, prog, 1).numpy())
+    for gs in (0, 10, 7000):
+        assert cfg.s_val(gs) == O.s_val_at(scene, gs)
+        assert dynamic_weight(1e-1, 1e-3, gs, 10000) == O.dynamic_weight(1e-1, 1e-3, gs, 10000)
+    assert math.isclose(dynamic_weight(1e-1, 1e-3, 10000, 10000), 1e-3)
