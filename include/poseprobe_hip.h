@@ -189,7 +189,7 @@ int pp_rgbnet_bwd(const float* params, const float* feat, const float* acts, con
 int pp_warp_fwd(const float* params, const float* pts, const int32_t* count, int32_t capacity, float out_range,
                 float* acts, float* out, void* stream);
 int pp_warp_bwd(const float* params, const float* pts, const float* acts, const float* out_grad,
-                const int32_t* count, int32_t capacity, float out_range, float* scratch /*[2][cap*4][128] + 49152*/,
+                const int32_t* count, int32_t capacity, float out_range, float* scratch /*[3][cap*4][128] + 49152*/,
                 float* params_grad /*atomic +=*/, float* pts_grad /* += */, void* ctx /*pp_context or NULL*/,
                 void* stream);
 

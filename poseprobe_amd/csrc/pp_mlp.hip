@@ -16,6 +16,8 @@
 // (reg&3) + 8*(reg>>2) + 4*(lane>>5): the four rows of a sample are registers 4q..4q+3 of the same lane, so the
 // 4-row masking needs no cross-lane traffic.
 #include "pp_common.h"
+#include "pp_mlp_fused.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -530,6 +532,13 @@ struct SideLane {
   }
 };
 
+// PP_MLP_FUSED=0 selects the layer-by-layer kernels (A/B measurements, generic shapes always use them)
+static bool mlp_fused_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PP_MLP_FUSED"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 static const int GEMM_MAX_WG = 256 * 5;     // 5 resident work-groups per CU at BM=64 (25 KB LDS, 90 regs)
 static const int GEMM_MAX_WG_SHARED = 256 * 3;   // when a weight-gradient GEMM runs beside it (register file: 2 x 96 + 2 x 144)
 static inline int gemm_grid(int rows, int bm, bool shared = false) {
@@ -629,6 +638,11 @@ extern "C" int pp_warp_fwd(const float* params, const float* pts, const int32_t*
   PP_REQUIRE(params && pts && count && acts && out, "null pointer");
   PP_REQUIRE(capacity > 0, "capacity<=0");
   hipStream_t st = pp_stream(stream);
+  if (mlp_fused_enabled()) {
+    pp_launch_warp_fused_fwd(params, pts, count, capacity, out_range, acts, out, st);
+    PP_CHECK_LAUNCH();
+    return PP_OK;
+  }
   const int rcap = capacity * 4;
   const size_t LS = (size_t)rcap * 128;
   dim3 g(gemm_grid(rcap, PP_GEMM_BM)), b(256);
@@ -652,9 +666,20 @@ extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* a
   PP_REQUIRE(params && pts && acts && out_grad && count && scratch && params_grad && pts_grad, "null pointer");
   PP_REQUIRE(capacity > 0, "capacity<=0");
   hipStream_t st = pp_stream(stream);
-  SideLane side(ctx, st);
   const int rcap = capacity * 4;
   const size_t LS = (size_t)rcap * 128;
+  if (mlp_fused_enabled()) {
+    // one fused data-gradient kernel (+ thin layers), then the three weight-gradient GEMMs on the Ybar it left behind
+    pp_launch_warp_fused_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad, st);
+    const int w_off[4] = {0, WP_W1, WP_W2, WP_W3};
+    const int b_off[4] = {0, WP_B1, WP_B2, WP_B3};
+    for (int l = 3; l >= 1; --l)
+      hipLaunchKernelGGL((k_gemm_tn<4>), dim3(TN_WGS), dim3(256), 0, st, scratch + (size_t)(3 - l) * LS, acts + (l - 1) * LS, 128,
+                         128, params_grad + w_off[l], 128, params_grad + b_off[l], count, 4, rcap);
+    PP_CHECK_LAUNCH();
+    return PP_OK;
+  }
+  SideLane side(ctx, st);
   float* cur = scratch;
   float* nxt = scratch + LS;
   float* wt = scratch + 2 * LS;          // transposed weights W3^T, W2^T, W1^T

@@ -114,7 +114,7 @@ class Workspace:
         self.g_gradient, self.g_pts, self.g_view_s = e(capacity, 3, **f), e(capacity, 3, **f), e(capacity, 3, **f)
         self.g_grad_deform, self.g_corr, self.g_sdf_deform = e(capacity, 9, **f), e(capacity, **f), e(capacity, **f)
         self.g_warp_out = e(capacity, 16, **f)
-        self.scratch = e(2 * capacity * 4 * 128 + 49152, **f)   # shared by both MLP backward chains (+ transposed weights)
+        self.scratch = e(3 * capacity * 4 * 128 + 49152, **f)   # shared by both MLP backward chains (+ transposed weights)
         self.g_rays_o, self.g_rays_d, self.g_viewdirs = e(N, 3, **f), e(N, 3, **f), e(N, 3, **f)
 
 
