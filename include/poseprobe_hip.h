@@ -177,7 +177,7 @@ int pp_context_destroy(void* ctx);
 int pp_rgbnet_fwd(const float* params, const float* feat, const int32_t* count, int32_t capacity, float* acts,
                   float* rgb, void* stream);
 int pp_rgbnet_bwd(const float* params, const float* feat, const float* acts, const float* rgb,
-                  const float* rgb_grad, const int32_t* count, int32_t capacity, float* scratch /*[2][cap][128] + 49152*/,
+                  const float* rgb_grad, const int32_t* count, int32_t capacity, float* scratch /*[3][cap][128] + 49152*/,
                   float* params_grad /*atomic +=*/, float* feat_grad, void* ctx /*pp_context or NULL*/, void* stream);
 
 /* warp MLP (DeformedImplicitField, lib/deformation/deform_net.py:12-31, modules.py:43-124): 3->128x4->4 ReLU,
@@ -285,7 +285,7 @@ int pp_feat_generic_bwd_k0(const pp_scene* sc, const float* pts, const uint8_t* 
 /* Generic ReLU MLP in_ld -> 128 x n_gemm -> 3 + sigmoid on the matrix cores.  Parameter block:
  * W0[128*in_ld] b0[128] | (W[128*128] b[128]) x (n_gemm-1) | Wout[3*128] bout[3].  logit_add[M,ld] (optional) is
  * added to the logits before the sigmoid (k0_diffuse, dvgo_ori.py:359).  acts[n_gemm][cap][128];
- * scratch [2][cap][128] + 16384. */
+ * scratch [3][cap][128] + 16384. */
 int pp_mlp_fwd(const float* params, const float* feat, int32_t in_ld, int32_t n_gemm, const int32_t* count,
                int32_t capacity, const float* logit_add, int32_t logit_add_ld, float* acts, float* out,
                void* stream);

@@ -560,6 +560,11 @@ extern "C" int pp_mlp_fwd(const float* params, const float* feat, int32_t in_ld,
   PP_REQUIRE(params && feat && count && acts && out, "null pointer");
   PP_REQUIRE(capacity > 0 && in_ld % 32 == 0 && in_ld <= 128 && n_gemm >= 1 && n_gemm <= 8, "bad sizes");
   hipStream_t st = pp_stream(stream);
+  if (in_ld == 64 && n_gemm == 3 && mlp_fused_enabled()) {       // the Voxurf rgbnet shape: layer-fused kernel
+    pp_launch_rgb_fused_fwd(params, feat, count, capacity, logit_add, logit_add_ld, acts, out, st);
+    PP_CHECK_LAUNCH();
+    return PP_OK;
+  }
   const size_t LS = (size_t)capacity * 128;
   dim3 g(gemm_grid(capacity, PP_GEMM_BM)), b(256);
   hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI_RELU, 1, PP_GEMM_BM>), g, b, 0, st, feat, in_ld, params, in_ld, in_ld, 128,
@@ -583,6 +588,12 @@ extern "C" int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld,
   PP_REQUIRE(params && feat && acts && out && out_grad && count && scratch && params_grad, "null pointer");
   PP_REQUIRE(capacity > 0 && in_ld % 32 == 0 && in_ld <= 128 && n_gemm >= 1 && n_gemm <= 8, "bad sizes");
   hipStream_t st = pp_stream(stream);
+  if (in_ld == 64 && n_gemm == 3 && feat_grad && mlp_fused_enabled()) {
+    pp_launch_rgb_fused_bwd(params, feat, acts, out, out_grad, count, capacity, scratch, params_grad, feat_grad,
+                            logit_add_grad, logit_add_ld, st);
+    PP_CHECK_LAUNCH();
+    return PP_OK;
+  }
   SideLane side(ctx, st);
   const size_t LS = (size_t)capacity * 128;
   float* cur = scratch;
@@ -671,11 +682,8 @@ extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* a
   if (mlp_fused_enabled()) {
     // one fused data-gradient kernel (+ thin layers), then the three weight-gradient GEMMs on the Ybar it left behind
     pp_launch_warp_fused_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad, st);
-    const int w_off[4] = {0, WP_W1, WP_W2, WP_W3};
-    const int b_off[4] = {0, WP_B1, WP_B2, WP_B3};
-    for (int l = 3; l >= 1; --l)
-      hipLaunchKernelGGL((k_gemm_tn<4>), dim3(TN_WGS), dim3(256), 0, st, scratch + (size_t)(3 - l) * LS, acts + (l - 1) * LS, 128,
-                         128, params_grad + w_off[l], 128, params_grad + b_off[l], count, 4, rcap);
+    pp_launch_wgrad_chain(scratch, acts + 2 * LS, params_grad + WP_W3, scratch + LS, acts + LS, params_grad + WP_W2,
+                          scratch + 2 * LS, acts, params_grad + WP_W1, 128, count, 4, rcap, st);
     PP_CHECK_LAUNCH();
     return PP_OK;
   }

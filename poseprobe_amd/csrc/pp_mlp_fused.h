@@ -23,3 +23,23 @@ int pp_launch_warp_fused_fwd(const float* params, const float* pts, const int32_
 int pp_launch_warp_fused_bwd(const float* params, const float* pts, const float* acts, const float* out_grad,
                              const int32_t* count, int capacity, float out_range, float* ybar, float* params_grad,
                              float* pts_grad, hipStream_t st);
+// weight gradients of three layers (Y_l^T X_l accumulated into W_l) in one persistent kernel; kxc = width of X of layer C
+int pp_launch_wgrad_chain(const float* YA, const float* XA, float* WA, const float* YB, const float* XB, float* WB,
+                          const float* YC, const float* XC, float* WC, int kxc, const int32_t* count, int rmul, int rcap,
+                          hipStream_t st);
+
+// parameter block of rgbnet (64-wide padded input): W0[128x64] b0 | W1[128x128] b1 | W2[128x128] b2 | W3[3x128] b3
+#define RGF_W0 0
+#define RGF_B0 (128 * 64)
+#define RGF_W1 (RGF_B0 + 128)
+#define RGF_B1 (RGF_W1 + 128 * 128)
+#define RGF_W2 (RGF_B1 + 128)
+#define RGF_B2 (RGF_W2 + 128 * 128)
+#define RGF_W3 (RGF_B2 + 128)
+#define RGF_B3 (RGF_W3 + 3 * 128)
+
+int pp_launch_rgb_fused_fwd(const float* params, const float* feat, const int32_t* count, int capacity,
+                            const float* logit_add, int add_ld, float* acts, float* rgb, hipStream_t st);
+int pp_launch_rgb_fused_bwd(const float* params, const float* feat, const float* acts, const float* rgb,
+                            const float* rgb_grad, const int32_t* count, int capacity, float* ybar, float* params_grad,
+                            float* feat_grad, float* logit_grad, int lg_ld, hipStream_t st);

@@ -13,10 +13,15 @@
 // D: feature l31, rows (reg&3) + 8(reg>>2) + 4lh -> the 4 rows of a warp sample sit in 4 registers of one lane.
 #include "pp_common.h"
 #include "pp_mlp_fused.h"
+#include "pp_wgrad_asm.inc"
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PP_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define PP_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define PP_WAIT_VMEM() do { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while (0)   /* vmcnt(0) only (gfx9 encoding) */
 
 #define LDA 132                 // LDS row stride of an activation tile (floats): 16-B aligned, 4-bank skew per row
 #define TILE_ROWS 64
@@ -119,7 +124,7 @@ __device__ __forceinline__ void relu_epilogue(const f32x16 (&acc)[2], float bcol
 // ReLU state (mk > 0, one value per sample = 4 rows); next A tile to LDS, optional copy to HBM for the weight-gradient GEMM.
 template <bool FULL, bool TOGLOBAL>
 __device__ __forceinline__ void mask_epilogue_impl(const f32x16 (&acc)[2], const float (&mk)[2][4], int r0, int R, int col,
-                                                   int lh, float* __restrict__ C, float* __restrict__ Anext) {
+                                                   int lh, float* __restrict__ C, float* __restrict__ Anext, float& bsum) {
   float* __restrict__ Ct = C + (size_t)r0 * 128;
   const unsigned lane_off = (unsigned)(4 * lh) * 128u + (unsigned)col;
   float* __restrict__ At = Anext + (4 * lh) * LDA + col;
@@ -132,6 +137,7 @@ __device__ __forceinline__ void mask_epilogue_impl(const f32x16 (&acc)[2], const
       for (int c = 0; c < 4; ++c) {
         const int row = t * 32 + 8 * q + c;
         const float v = on ? acc[t][4 * q + c] : 0.f;
+        if (c == 0) bsum += v;                              // bias gradient: primal rows only (rows past R are zero)
         At[row * LDA] = v;
         if (TOGLOBAL && (FULL || r0 + row + 4 * lh < R)) Ct[lane_off + (unsigned)(row * 128)] = v;
       }
@@ -141,9 +147,9 @@ __device__ __forceinline__ void mask_epilogue_impl(const f32x16 (&acc)[2], const
 
 template <bool TOGLOBAL>
 __device__ __forceinline__ void mask_epilogue(const f32x16 (&acc)[2], const float (&mk)[2][4], int r0, int R, int col, int lh,
-                                              float* __restrict__ C, float* __restrict__ Anext) {
-  if (r0 + TILE_ROWS <= R) mask_epilogue_impl<true, TOGLOBAL>(acc, mk, r0, R, col, lh, C, Anext);
-  else mask_epilogue_impl<false, TOGLOBAL>(acc, mk, r0, R, col, lh, C, Anext);
+                                              float* __restrict__ C, float* __restrict__ Anext, float& bsum) {
+  if (r0 + TILE_ROWS <= R) mask_epilogue_impl<true, TOGLOBAL>(acc, mk, r0, R, col, lh, C, Anext, bsum);
+  else mask_epilogue_impl<false, TOGLOBAL>(acc, mk, r0, R, col, lh, C, Anext, bsum);
 }
 
 // primal-row activations (one per sample) that gate the 8 samples a lane owns in the accumulator layout
@@ -309,9 +315,6 @@ int pp_launch_warp_fused_fwd(const float* params, const float* pts, const int32_
 // register-staged prefetch would be parked in accumulator registers by the compiler (= waited for on the spot), and on
 // gfx9 any wait for a vector load is a vmcnt(0) that also drains the activation stores in flight.  LDS-direct loads are
 // issued one MFMA block (or one tile) ahead of their single explicit wait, by which time those stores have retired.
-#define PP_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
-#define PP_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-#define PP_WAIT_VMEM() do { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while (0)   /* vmcnt(0) only (gfx9 encoding) */
 
 __global__ __launch_bounds__(256) void k_warp_fused_bwd(const float* __restrict__ params, const float* __restrict__ pts,
                                                         const float* __restrict__ acts,
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd(const float* __restrict_
     W0s[r * LDA + j] = (r < 3) ? params[WPF_W0 + j * 3 + r] : 0.f;
   }
   float wacc4[4] = {0.f, 0.f, 0.f, 0.f}, bacc4 = 0.f, wacc0[3] = {0.f, 0.f, 0.f}, bacc0 = 0.f;
+  float bacc3 = 0.f, bacc2 = 0.f, bacc1 = 0.f, bdummy = 0.f;   // bias gradients of the hidden layers (bacc3: thread = feature)
 
   // ---- LDS-direct staging of tile t into parity slot b: X3 rows -> XS, out_grad -> G[b], positions -> Ps[b].
   // Rows / samples past the end are clamped to the last valid one; their out_grad slot is zeroed after the wait, which
@@ -409,6 +413,7 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd(const float* __restrict_
           wacc4[0] += g.x * x; wacc4[1] += g.y * x; wacc4[2] += g.z * x; wacc4[3] += g.w * x;
           const float yb = g.x * w4a + g.y * w4b + g.z * w4c + g.w * w4d;
           const float v = on ? yb : 0.f;
+          if (c == 0) bacc3 += v;
           at[(4 * q + c) * LDA] = v;
           if (ok) yt[off + q * 512 + c * 128] = v;
         }
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd(const float* __restrict_
     mma_tile<128>(As[0], w3, acc, l31, lh);
     PP_WAIT_VMEM();
     read_masks(mk);
-    mask_epilogue<true>(acc, mk, r0, R, col, lh, ybar + LS, As[1]);
+    mask_epilogue<true>(acc, mk, r0, R, col, lh, ybar + LS, As[1], bacc2);
     stage_masks(X1, r0);                             // (each lane overwrites only its own, already consumed, slots)
     __syncthreads();
     // ---- layer 2
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd(const float* __restrict_
     mma_tile<128>(As[1], w2, acc, l31, lh);
     PP_WAIT_VMEM();
     read_masks(mk);
-    mask_epilogue<true>(acc, mk, r0, R, col, lh, ybar + 2 * LS, As[2]);
+    mask_epilogue<true>(acc, mk, r0, R, col, lh, ybar + 2 * LS, As[2], bacc1);
     stage_masks(X0, r0);
     __syncthreads();
     // ---- layer 1: Ybar0 stays in LDS
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd(const float* __restrict_
     mma_tile<128>(As[2], w1, acc, l31, lh);
     PP_WAIT_VMEM();                                  // also covers stage(tnext): XS / G / Ps of the next tile have landed
     read_masks(mk);
-    mask_epilogue<false>(acc, mk, r0, R, col, lh, ybar, As[1]);
+    mask_epilogue<false>(acc, mk, r0, R, col, lh, ybar, As[1], bdummy);
     __syncthreads();
     // ---- layer 0: W0bar[j][i] += Ybar0[4s][j] p_i + Ybar0[4s+1+i][j], b0bar[j] += Ybar0[4s][j]  (thread = feature j)
     {
@@ -516,6 +521,7 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd(const float* __restrict_
     for (int i = 0; i < 3; ++i) red[(4 + i) * 128 + j0] = wacc0[i];
     red[7 * 128 + j0] = bacc0;
     if (j0 < 4) red[8 * 128 + j0] = bacc4;
+    red[9 * 128 + j0] = bacc3;
   }
   __syncthreads();
   if (h0 == 0) {
@@ -525,6 +531,14 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd(const float* __restrict_
     for (int i = 0; i < 3; ++i) atomicAdd(&params_grad[WPF_W0 + j0 * 3 + i], wacc0[i] + red[(4 + i) * 128 + j0]);
     atomicAdd(&params_grad[WPF_B0 + j0], bacc0 + red[7 * 128 + j0]);
     if (j0 < 4) atomicAdd(&params_grad[WPF_B4 + j0], (bacc4 + red[8 * 128 + j0]) * out_range);
+    atomicAdd(&params_grad[WPF_B3 + j0], bacc3 + red[9 * 128 + j0]);
+  }
+  // b2 / b1: lane = (feature col, row half lh)
+  bacc2 += __shfl_xor(bacc2, 32, 64);
+  bacc1 += __shfl_xor(bacc1, 32, 64);
+  if (lh == 0) {
+    atomicAdd(&params_grad[WPF_B2 + col], bacc2);
+    atomicAdd(&params_grad[WPF_B1 + col], bacc1);
   }
 }
 
@@ -537,3 +551,527 @@ int pp_launch_warp_fused_bwd(const float* params, const float* pts, const float*
                      ybar, params_grad, pts_grad);
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ weight gradients
+// Wbar_l[n][k] += sum_r Ybar_l[r][n] * X_l[r][k]  for up to three layers in ONE persistent kernel.  A step = one 64-row
+// tile of one layer: both operand tiles arrive by LDS-direct loads (no register staging) into a double buffer while the
+// previous step is on the matrix cores; the 128 x KX accumulators of all layers stay in (accumulator) registers over
+// the whole row range of the work-group and are flushed with one atomic per entry at the end.  Both MFMA operands
+// are read row-wise (k = row), so the unpadded lane-contiguous layout of the LDS-direct loads is conflict-free.
+struct WgradLayer {
+  const float* Y;      // [R][128]   gradient w.r.t. the layer's pre-activation (already gated)
+  const float* X;      // [R][KX]    input activations of the layer
+  float* Wbar;         // [128][KX]
+};
+
+namespace {
+
+template <int KX>
+__device__ __forceinline__ void wgrad_issue(const WgradLayer& L, int r0, int R, float* Ybuf, float* Xbuf, int wid, int lane) {
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int rl = 16 * wid + 2 * i;
+    const int row = min(r0 + rl + lh, R - 1);
+    __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(L.Y + (size_t)row * 128 + l31 * 4), PP_LDS_PTR(Ybuf + rl * 128), 16, 0, 0);
+  }
+  if (KX == 128) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = 16 * wid + 2 * i;
+      const int row = min(r0 + rl + lh, R - 1);
+      __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(L.X + (size_t)row * 128 + l31 * 4), PP_LDS_PTR(Xbuf + rl * 128), 16, 0, 0);
+    }
+  } else {               // KX == 64: four 256-byte rows per instruction
+    const int l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = 16 * wid + 4 * i;
+      const int row = min(r0 + rl + lq, R - 1);
+      __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(L.X + (size_t)row * 64 + l15 * 4), PP_LDS_PTR(Xbuf + rl * 64), 16, 0, 0);
+    }
+  }
+}
+
+// 64 rows x (128 x KX) on the matrix cores; hand-scheduled (tools/gen_wgrad_asm.py -> pp_wgrad_asm.inc)
+template <int KX>
+__device__ __forceinline__ void wgrad_compute(const float* __restrict__ Ybuf, const float* __restrict__ Xbuf,
+                                              f32x16 (&acc)[2][KX / 64], int wr, int wc, int l31, int lh) {
+  constexpr int NB = KX / 64;
+  // 32-bit LDS byte addresses of this lane's operand streams (row parity lh, feature l31)
+  const unsigned y = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)(Ybuf + lh * 128 + 64 * wr + l31);
+  const unsigned x = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)(Xbuf + lh * KX + 32 * NB * wc + l31);
+  float a00, a10, b00, b10, a01, a11, b01, b11;
+  if constexpr (NB == 2) {
+    asm volatile(PP_WGRAD_BLOCK_NB2
+                 : [c00] "+a"(acc[0][0]), [c10] "+a"(acc[1][0]), [c01] "+a"(acc[0][1]), [c11] "+a"(acc[1][1]),
+                   [a00] "=&v"(a00), [a10] "=&v"(a10), [b00] "=&v"(b00), [b10] "=&v"(b10),
+                   [a01] "=&v"(a01), [a11] "=&v"(a11), [b01] "=&v"(b01), [b11] "=&v"(b11)
+                 : [y] "v"(y), [x] "v"(x)
+                 : "memory");
+  } else {
+    asm volatile(PP_WGRAD_BLOCK_NB1
+                 : [c00] "+a"(acc[0][0]), [c10] "+a"(acc[1][0]),
+                   [a00] "=&v"(a00), [a10] "=&v"(a10), [b00] "=&v"(b00),
+                   [a01] "=&v"(a01), [a11] "=&v"(a11), [b01] "=&v"(b01)
+                 : [y] "v"(y), [x] "v"(x)
+                 : "memory");
+  }
+}
+
+template <int KX>
+__device__ __forceinline__ void wgrad_flush(float* __restrict__ Wbar, const f32x16 (&acc)[2][KX / 64], int wr, int wc, int l31, int lh) {
+  constexpr int NB = KX / 64;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int k = 32 * NB * wc + u * 32 + l31;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int n = wr * 64 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        atomicAdd(&Wbar[(size_t)n * KX + k], acc[t][u][reg]);
+      }
+    }
+}
+
+template <int KX>
+__device__ __forceinline__ void zero_acc2(f32x16 (&acc)[2][KX / 64]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < KX / 64; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+}
+
+}  // namespace
+
+// One pipeline step: start the LDS-direct loads of the NEXT step into (Ydst, Xdst), then run the matrix cores on the
+// tiles already sitting in (Ysrc, Xsrc).  The __restrict__ qualifiers matter: after inlining they become alias scopes
+// on the LDS-DMA writes and the ds_reads, which lets the compiler's wait-count pass see that the reads do not depend on
+// the loads just issued (otherwise it inserts a vmcnt(0) in front of the first ds_read and the overlap is gone).
+template <int KXN, int KXS>
+__device__ __forceinline__ void wgrad_step(bool issue, const WgradLayer& Ln, int r0n, int R, float* __restrict__ Ydst,
+                                           float* __restrict__ Xdst, const float* __restrict__ Ysrc,
+                                           const float* __restrict__ Xsrc, f32x16 (&acc)[2][KXS / 64], int wid, int lane) {
+  if (issue) wgrad_issue<KXN>(Ln, r0n, R, Ydst, Xdst, wid, lane);
+  wgrad_compute<KXS>(Ysrc, Xsrc, acc, wid >> 1, wid & 1, lane & 31, lane >> 5);
+}
+
+// layers A, B: KX = 128; layer C: KX = KXC (128 for the warp net, 64 for rgbnet's input layer)
+template <int KXC>
+__global__ __launch_bounds__(256) void k_wgrad_chain(WgradLayer LA, WgradLayer LB, WgradLayer LC,
+                                                     const int32_t* __restrict__ count, int rmul, int rcap) {
+  __shared__ __attribute__((aligned(16))) float Yb0[TILE_ROWS * 128];
+  __shared__ __attribute__((aligned(16))) float Xb0[TILE_ROWS * 128];
+  __shared__ __attribute__((aligned(16))) float Yb1[TILE_ROWS * 128];
+  __shared__ __attribute__((aligned(16))) float Xb1[TILE_ROWS * 128];
+  const int R = min(count[0] * rmul, rcap);
+  const int ntiles = (R + TILE_ROWS - 1) / TILE_ROWS;
+  if ((int)blockIdx.x * 2 >= ntiles) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, lh = lane >> 5;
+  f32x16 accA[2][2], accB[2][2], accC[2][KXC / 64];
+  zero_acc2<128>(accA); zero_acc2<128>(accB); zero_acc2<KXC>(accC);
+
+  // rows past R are fetched clamped; their Y rows are zeroed in LDS before use (last tile only)
+  auto fix_tail = [&](int r0, float* Ybuf) {
+    if (r0 + TILE_ROWS > R) {
+      for (int i = tid; i < TILE_ROWS * 128; i += 256)
+        if (r0 + (i >> 7) >= R) Ybuf[i] = 0.f;
+      __syncthreads();
+    }
+  };
+  // Six steps per iteration keep the buffer assignment static: A0 B1 C0 | A1 B0 C1.  The unit of work is a PAIR of
+  // adjacent tiles, so only the very last pair can contain an empty tile (rows clamped, Y zeroed by fix_tail);
+  // straight-line control flow keeps the 192 accumulator registers pinned across the hand-scheduled blocks.
+  const int npairs = (ntiles + 1) >> 1;
+  wgrad_issue<128>(LA, blockIdx.x * 2 * TILE_ROWS, R, Yb0, Xb0, wid, lane);
+  for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+    const int r0 = pair * 2 * TILE_ROWS;
+    const int r1 = r0 + TILE_ROWS;
+    const int t2 = pair + gridDim.x;
+    PP_WAIT_VMEM(); __syncthreads();
+    fix_tail(r0, Yb0);
+    wgrad_step<128, 128>(true, LB, r0, R, Yb1, Xb1, Yb0, Xb0, accA, wid, lane);
+    PP_WAIT_VMEM(); __syncthreads();
+    fix_tail(r0, Yb1);
+    wgrad_step<KXC, 128>(true, LC, r0, R, Yb0, Xb0, Yb1, Xb1, accB, wid, lane);
+    PP_WAIT_VMEM(); __syncthreads();
+    fix_tail(r0, Yb0);
+    wgrad_step<128, KXC>(true, LA, r1, R, Yb1, Xb1, Yb0, Xb0, accC, wid, lane);
+    PP_WAIT_VMEM(); __syncthreads();
+    fix_tail(r1, Yb1);
+    wgrad_step<128, 128>(true, LB, r1, R, Yb0, Xb0, Yb1, Xb1, accA, wid, lane);
+    PP_WAIT_VMEM(); __syncthreads();
+    fix_tail(r1, Yb0);
+    wgrad_step<KXC, 128>(true, LC, r1, R, Yb1, Xb1, Yb0, Xb0, accB, wid, lane);
+    PP_WAIT_VMEM(); __syncthreads();
+    fix_tail(r1, Yb1);
+    wgrad_step<128, KXC>(t2 < npairs, LA, t2 * 2 * TILE_ROWS, R, Yb0, Xb0, Yb1, Xb1, accC, wid, lane);
+  }
+  wgrad_flush<128>(LA.Wbar, accA, wr, wc, l31, lh);
+  wgrad_flush<128>(LB.Wbar, accB, wr, wc, l31, lh);
+  wgrad_flush<KXC>(LC.Wbar, accC, wr, wc, l31, lh);
+}
+
+int pp_launch_wgrad_chain(const float* YA, const float* XA, float* WA, const float* YB, const float* XB, float* WB,
+                          const float* YC, const float* XC, float* WC, int kxc, const int32_t* count, int rmul, int rcap,
+                          hipStream_t st) {
+  WgradLayer LA{YA, XA, WA}, LB{YB, XB, WB}, LC{YC, XC, WC};
+  const int npairs = pp_div_up(rcap, 2 * TILE_ROWS);
+  const int grid = npairs < PP_FUSED_WGS ? npairs : PP_FUSED_WGS;
+  if (kxc == 128)
+    hipLaunchKernelGGL((k_wgrad_chain<128>), dim3(grid), dim3(256), 0, st, LA, LB, LC, count, rmul, rcap);
+  else
+    hipLaunchKernelGGL((k_wgrad_chain<64>), dim3(grid), dim3(256), 0, st, LA, LB, LC, count, rmul, rcap);
+  return 0;
+}
+// ================================================================================================ rgbnet (64 -> 128 x3 -> 3)
+namespace {
+
+// LDS-direct load of a [64][64] tile of 256-byte rows into an UNPADDED buffer whose 16-byte slots are XOR-swizzled:
+// element (row, c4) lives in slot row*16 + (c4 ^ (row & 15)).  The permutation is applied on the global-address side
+// (which quad a lane fetches), the LDS side of an LDS-direct load is always lane-contiguous.  With it the MFMA
+// A-operand reads (8 consecutive rows per LDS phase, same c4) hit 8 different bank groups, like the padded tiles.
+__device__ __forceinline__ void stage_feat_tile(const float* __restrict__ feat, int r0, int R, float* Fs, int wid, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl = 16 * wid + 4 * i + (lane >> 4);            // four rows per instruction
+    const int c4 = (lane & 15) ^ (rl & 15);
+    const int row = min(r0 + rl, R - 1);
+    __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(feat + (size_t)row * 64 + c4 * 4), PP_LDS_PTR(Fs + (16 * wid + 4 * i) * 64), 16, 0, 0);
+  }
+}
+
+// acc[t] += F[t*32 + l31][0:64] . w   (swizzled feature tile, K = 64)
+__device__ __forceinline__ void mma_feat_tile(const float* __restrict__ Fs, const float4 (&w)[8], f32x16 (&acc)[2], int l31, int lh) {
+  const int sw = l31 & 15;
+  const float* f0 = Fs + l31 * 64;
+  const float* f1 = f0 + 32 * 64;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int c4 = ((2 * g + lh) ^ sw) * 4;
+    const float4 a0 = *reinterpret_cast<const float4*>(f0 + c4);
+    const float4 a1 = *reinterpret_cast<const float4*>(f1 + c4);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, w[g].x, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, w[g].x, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, w[g].y, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, w[g].y, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, w[g].z, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, w[g].z, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, w[g].w, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, w[g].w, acc[1], 0, 0, 0);
+  }
+}
+
+// two rows (2 x 512 B) per instruction, 8 instructions per wavefront: a [64][128] tile, unpadded, rows clamped to R-1
+__device__ __forceinline__ void stage_tile128(const float* __restrict__ X, int r0, int R, float* dst, int wid, int lane) {
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int rl = 16 * wid + 2 * i;
+    const int row = min(r0 + rl + lh, R - 1);
+    __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(X + (size_t)row * 128 + l31 * 4), PP_LDS_PTR(dst + rl * 128), 16, 0, 0);
+  }
+}
+
+// backward-data epilogue with one ReLU gate per element (gates = the layer input's activations, tile in LDS)
+template <bool FULL, bool TOGLOBAL>
+__device__ __forceinline__ void gate_epilogue_impl(const f32x16 (&acc)[2], const float* __restrict__ Gt, int r0, int R, int col,
+                                                   int lh, float* __restrict__ C, float* __restrict__ Anext, float& bsum) {
+  float* __restrict__ Ct = C + (size_t)r0 * 128;
+  const unsigned lane_off = (unsigned)(4 * lh) * 128u + (unsigned)col;
+  float* __restrict__ At = Anext + (4 * lh) * LDA + col;
+  const float* __restrict__ gt = Gt + (4 * lh) * 128 + col;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = t * 32 + (reg & 3) + 8 * (reg >> 2);
+      const float v = (gt[row * 128] > 0.f) ? acc[t][reg] : 0.f;
+      bsum += v;
+      At[row * LDA] = v;
+      if (TOGLOBAL && (FULL || r0 + row + 4 * lh < R)) Ct[lane_off + (unsigned)(row * 128)] = v;
+    }
+  }
+}
+template <bool TOGLOBAL>
+__device__ __forceinline__ void gate_epilogue(const f32x16 (&acc)[2], const float* __restrict__ Gt, int r0, int R, int col, int lh,
+                                              float* __restrict__ C, float* __restrict__ Anext, float& bsum) {
+  if (r0 + TILE_ROWS <= R) gate_epilogue_impl<true, TOGLOBAL>(acc, Gt, r0, R, col, lh, C, Anext, bsum);
+  else gate_epilogue_impl<false, TOGLOBAL>(acc, Gt, r0, R, col, lh, C, Anext, bsum);
+}
+
+}  // namespace
+
+// feat[M][64] -> rgb[M][3] = sigmoid(MLP(feat) (+ logit_add)); hidden activations H0..H2 ([cap][128] each) kept for backward
+__global__ __launch_bounds__(256) void k_rgb_fused_fwd(const float* __restrict__ params, const float* __restrict__ feat,
+                                                       const int32_t* __restrict__ count, int capacity,
+                                                       const float* __restrict__ logit_add, int add_ld,
+                                                       float* __restrict__ acts, float* __restrict__ rgb) {
+  __shared__ __attribute__((aligned(16))) float As[2][TILE_ROWS * LDA];
+  __shared__ __attribute__((aligned(16))) float Fs[2][TILE_ROWS * 64];
+  __shared__ __attribute__((aligned(16))) float W3s[4 * LDA];
+  __shared__ __attribute__((aligned(16))) float Red[4 * 64 * 4];
+  const int R = min(count[0], capacity);
+  const int ntiles = (R + TILE_ROWS - 1) / TILE_ROWS;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int col = wid * 32 + l31;
+  const size_t LS = (size_t)capacity * 128;
+
+  float4 w0[8], w1[16], w2[16];
+  load_w_rows<64>(w0, params + RGF_W0, 64, col, lh);
+  load_w_rows<128>(w1, params + RGF_W1, 128, col, lh);
+  load_w_rows<128>(w2, params + RGF_W2, 128, col, lh);
+  const float b0 = params[RGF_B0 + col], b1 = params[RGF_B1 + col], b2 = params[RGF_B2 + col];
+  for (int i = tid; i < 512; i += 256) {
+    const int r = i >> 7, j = i & 127;
+    W3s[r * LDA + j] = (r < 3) ? params[RGF_W3 + r * 128 + j] : 0.f;
+  }
+  const float b3 = ((tid & 3) < 3) ? params[RGF_B3 + (tid & 3)] : 0.f;
+
+  stage_feat_tile(feat, blockIdx.x * TILE_ROWS, R, Fs[0], wid, lane);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  int par = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
+    const int r0 = tile * TILE_ROWS;
+    const int tnext = tile + gridDim.x;
+    if (tnext < ntiles) stage_feat_tile(feat, tnext * TILE_ROWS, R, Fs[par ^ 1], wid, lane);   // lands during this tile
+    f32x16 acc[2];
+    zero_acc(acc);
+    mma_feat_tile(Fs[par], w0, acc, l31, lh);
+    relu_epilogue<1>(acc, b0, r0, R, col, lh, acts, As[0]);
+    __syncthreads();
+    zero_acc(acc);
+    mma_tile<128>(As[0], w1, acc, l31, lh);
+    relu_epilogue<1>(acc, b1, r0, R, col, lh, acts + LS, As[1]);
+    __syncthreads();
+    zero_acc(acc);
+    mma_tile<128>(As[1], w2, acc, l31, lh);
+    PP_WAIT_VMEM();                      // next feature tile has landed (stores in flight are two MFMA blocks old)
+    relu_epilogue<1>(acc, b2, r0, R, col, lh, acts + 2 * LS, As[0]);
+    __syncthreads();
+    // output layer (128 -> 3) on v_mfma_f32_4x4x1: lane = row, lane&3 = output, K slice per wavefront
+    {
+      const float* xr = &As[0][lane * LDA + 32 * wid];
+      const float* wr = &W3s[(lane & 3) * LDA + 32 * wid];
+      float4 xv[8], wv[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        xv[g] = *reinterpret_cast<const float4*>(xr + 4 * g);
+        wv[g] = *reinterpret_cast<const float4*>(wr + 4 * g);
+      }
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].x, wv[g].x, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].y, wv[g].y, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].z, wv[g].z, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].w, wv[g].w, d1, 0, 0, 0);
+      }
+      *reinterpret_cast<float4*>(&Red[(wid * 64 + lane) * 4]) = make_float4(d0[0] + d1[0], d0[1] + d1[1], d0[2] + d1[2], d0[3] + d1[3]);
+    }
+    __syncthreads();
+    {
+      const int row = tid >> 2, o = tid & 3;
+      const int idx = ((row >> 2) * 4 + o) * 4 + (row & 3);
+      const float sum = (Red[idx] + Red[256 + idx]) + (Red[512 + idx] + Red[768 + idx]);
+      if (o < 3 && r0 + row < R) {
+        const size_t m = (size_t)(r0 + row);
+        rgb[m * 3 + o] = pp_sigmoid(sum + b3 + (logit_add ? logit_add[m * add_ld + o] : 0.f));
+      }
+    }
+  }
+}
+
+int pp_launch_rgb_fused_fwd(const float* params, const float* feat, const int32_t* count, int capacity,
+                            const float* logit_add, int add_ld, float* acts, float* rgb, hipStream_t st) {
+  const int ntiles = pp_div_up(capacity, TILE_ROWS);
+  const int grid = ntiles < PP_FUSED_WGS ? ntiles : PP_FUSED_WGS;
+  hipLaunchKernelGGL(k_rgb_fused_fwd, dim3(grid), dim3(256), 0, st, params, feat, count, capacity, logit_add, add_ld, acts, rgb);
+  return 0;
+}
+
+// Backward: output layer, the two 128x128 data-gradient products and the 128 -> 64 product onto the features in one
+// persistent kernel; Ybar2 / Ybar1 / Ybar0 go to `ybar` ([3][cap][128]) for k_wgrad_chain<64>; all bias gradients and
+// W3bar are accumulated in registers.
+__global__ __launch_bounds__(256) void k_rgb_fused_bwd(const float* __restrict__ params, const float* __restrict__ acts,
+                                                       const float* __restrict__ rgb, const float* __restrict__ rgb_grad,
+                                                       const int32_t* __restrict__ count, int capacity,
+                                                       float* __restrict__ ybar, float* __restrict__ params_grad,
+                                                       float* __restrict__ feat_grad, float* __restrict__ logit_grad, int lg_ld) {
+  __shared__ __attribute__((aligned(16))) float As[2][TILE_ROWS * LDA];
+  __shared__ __attribute__((aligned(16))) float XS[TILE_ROWS * 128];      // H2 of the NEXT tile
+  __shared__ __attribute__((aligned(16))) float GT[TILE_ROWS * 128];      // gates of the current layer (H1, then H0)
+  __shared__ __attribute__((aligned(16))) float RG[2][2][192];            // [parity][rgb | rgb_grad] of a tile
+  __shared__ __attribute__((aligned(16))) float GL[TILE_ROWS * 4];        // d loss / d logits of the staged tile
+  const int R = min(count[0], capacity);
+  const int ntiles = (R + TILE_ROWS - 1) / TILE_ROWS;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int col = wid * 32 + l31;
+  const size_t LS = (size_t)capacity * 128;
+  const float* __restrict__ H0 = acts;
+  const float* __restrict__ H1 = acts + LS;
+  const float* __restrict__ H2 = acts + 2 * LS;
+
+  float4 w2[16], w1[16], w0[16];
+  load_w_cols<128>(w2, params + RGF_W2, 128, col, lh);
+  load_w_cols<128>(w1, params + RGF_W1, 128, col, lh);
+  // last product: feat_grad[64 rows][64] = Ybar0 . W0, wavefront = (row block wid>>1, column block wid&1)
+  const int wr = wid >> 1, fcol = (wid & 1) * 32 + l31;
+  load_w_cols<128>(w0, params + RGF_W0, 64, fcol, lh);
+  const int j0 = tid & 127, h0 = tid >> 7;
+  const float w3a = params[RGF_W3 + j0], w3b = params[RGF_W3 + 128 + j0], w3c = params[RGF_W3 + 256 + j0];
+  float wacc3[3] = {0.f, 0.f, 0.f}, bacc3 = 0.f, bacc2 = 0.f, bacc1 = 0.f, bacc0 = 0.f;
+
+  auto stage = [&](int t, int b) {              // H2 rows, rgb and rgb_grad of tile t
+    const int r0 = t * TILE_ROWS;
+    stage_tile128(H2, r0, R, XS, wid, lane);
+    if (wid < 3) {
+      const int e = min(r0 * 3 + tid, R * 3 - 1);
+      __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(rgb + e), PP_LDS_PTR(&RG[b][0][wid * 64]), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(rgb_grad + e), PP_LDS_PTR(&RG[b][1][wid * 64]), 4, 0, 0);
+    }
+  };
+  // d loss / d logit = rgb_grad * rgb * (1 - rgb); zero for rows past the end (which zeroes everything downstream)
+  auto logit_grads = [&](int t, int b) {
+    const int r0 = t * TILE_ROWS;
+    if (tid < 192) {
+      const int m = tid / 3, o = tid - 3 * m;
+      const float r = RG[b][0][tid];
+      const float gl = (r0 + m < R) ? RG[b][1][tid] * r * (1.f - r) : 0.f;
+      GL[m * 4 + o] = gl;
+      if (logit_grad && r0 + m < R) logit_grad[(size_t)(r0 + m) * lg_ld + o] = gl;
+    } else {
+      GL[(tid - 192) * 4 + 3] = 0.f;
+    }
+  };
+  // output layer backward of the staged tile -> dst (+ HBM copy): thread = (feature j0, row half h0)
+  auto out_layer_bwd = [&](int t, float* __restrict__ dst) {
+    const int r0 = t * TILE_ROWS;
+    float* __restrict__ yt = ybar + (size_t)r0 * 128;
+    const unsigned off = (unsigned)(h0 * 32) * 128u + (unsigned)j0;
+    float* __restrict__ at = dst + (h0 * 32) * LDA + j0;
+    const float* __restrict__ xs = &XS[(h0 * 32) * 128 + j0];
+    auto body = [&](auto fc) {
+      constexpr bool FULL = decltype(fc)::value;
+#pragma unroll 8
+      for (int q = 0; q < 32; ++q) {
+        const float4 g = *reinterpret_cast<const float4*>(&GL[(h0 * 32 + q) * 4]);
+        const float x = xs[q * 128];
+        wacc3[0] += g.x * x; wacc3[1] += g.y * x; wacc3[2] += g.z * x;
+        const float hb = g.x * w3a + g.y * w3b + g.z * w3c;
+        const float v = (x > 0.f) ? hb : 0.f;
+        bacc2 += v;
+        at[q * LDA] = v;
+        if (FULL || r0 + h0 * 32 + q < R) yt[off + q * 128] = v;
+        if (j0 < 3) bacc3 += GL[(h0 * 32 + q) * 4 + j0];
+      }
+    };
+    PP_WITH_FULL(r0 + TILE_ROWS <= R, body);
+  };
+
+  stage(blockIdx.x, 0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  logit_grads(blockIdx.x, 0);
+  __syncthreads();
+  out_layer_bwd(blockIdx.x, As[0]);
+  __syncthreads();
+
+  int par = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
+    const int r0 = tile * TILE_ROWS;
+    const int tnext = tile + gridDim.x;
+    float* __restrict__ Aa = As[par];            // holds Ybar2 of this tile
+    float* __restrict__ Ab = As[par ^ 1];
+    if (tnext < ntiles) stage(tnext, par ^ 1);   // XS / RG[par^1]: consumed at the bottom of this iteration
+    stage_tile128(H1, r0, R, GT, wid, lane);
+    f32x16 acc[2];
+    // ---- layer 2: Ybar1 = gate(H1) . (Ybar2 W2)
+    zero_acc(acc);
+    mma_tile<128>(Aa, w2, acc, l31, lh);
+    PP_WAIT_VMEM();
+    __syncthreads();                             // gates come from all four wavefronts' loads
+    gate_epilogue<true>(acc, GT, r0, R, col, lh, ybar + LS, Ab, bacc1);
+    __syncthreads();
+    stage_tile128(H0, r0, R, GT, wid, lane);
+    // ---- layer 1: Ybar0 = gate(H0) . (Ybar1 W1)
+    zero_acc(acc);
+    mma_tile<128>(Ab, w1, acc, l31, lh);
+    PP_WAIT_VMEM();
+    __syncthreads();
+    gate_epilogue<true>(acc, GT, r0, R, col, lh, ybar + 2 * LS, Aa, bacc0);
+    if (tnext < ntiles) logit_grads(tnext, par ^ 1);
+    __syncthreads();
+    // ---- layer 0: feat_grad = Ybar0 . W0   (32 rows x 32 features per wavefront)
+    {
+      f32x16 fa;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) fa[i] = 0.f;
+      const float* ap = Aa + (wr * 32 + l31) * LDA + 4 * lh;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float4 a = *reinterpret_cast<const float4*>(ap + 8 * g);
+        fa = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w0[g].x, fa, 0, 0, 0);
+        fa = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w0[g].y, fa, 0, 0, 0);
+        fa = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w0[g].z, fa, 0, 0, 0);
+        fa = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w0[g].w, fa, 0, 0, 0);
+      }
+      float* __restrict__ ft = feat_grad + (size_t)r0 * 64;
+      const unsigned foff = (unsigned)(wr * 32 + 4 * lh) * 64u + (unsigned)fcol;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2);
+        if (r0 + wr * 32 + 4 * lh + row < R) ft[foff + (unsigned)(row * 64)] = fa[reg];
+      }
+    }
+    // ---- the next tile's output-layer backward into the buffer this tile started from (free since the first MFMA block;
+    // Aa is still being read by the feature-gradient product, so it goes to Ab, which the next iteration calls Aa)
+    if (tnext < ntiles) out_layer_bwd(tnext, Ab);
+    __syncthreads();
+  }
+
+  // ---- flush: W3bar, b3bar (thread = feature / output), b2bar (thread = feature); b1bar, b0bar (lane = feature, row half)
+  float* red = &As[0][0];
+  __syncthreads();
+  if (h0 == 1) {
+#pragma unroll
+    for (int o = 0; o < 3; ++o) red[o * 128 + j0] = wacc3[o];
+    red[3 * 128 + j0] = bacc2;
+    if (j0 < 3) red[4 * 128 + j0] = bacc3;
+  }
+  __syncthreads();
+  if (h0 == 0) {
+#pragma unroll
+    for (int o = 0; o < 3; ++o) atomicAdd(&params_grad[RGF_W3 + o * 128 + j0], wacc3[o] + red[o * 128 + j0]);
+    atomicAdd(&params_grad[RGF_B2 + j0], bacc2 + red[3 * 128 + j0]);
+    if (j0 < 3) atomicAdd(&params_grad[RGF_B3 + j0], bacc3 + red[4 * 128 + j0]);
+  }
+  bacc1 += __shfl_xor(bacc1, 32, 64);
+  bacc0 += __shfl_xor(bacc0, 32, 64);
+  if (lh == 0) {
+    atomicAdd(&params_grad[RGF_B1 + col], bacc1);
+    atomicAdd(&params_grad[RGF_B0 + col], bacc0);
+  }
+}
+
+int pp_launch_rgb_fused_bwd(const float* params, const float* feat, const float* acts, const float* rgb,
+                            const float* rgb_grad, const int32_t* count, int capacity, float* ybar, float* params_grad,
+                            float* feat_grad, float* logit_grad, int lg_ld, hipStream_t st) {
+  const int ntiles = pp_div_up(capacity, TILE_ROWS);
+  const int grid = ntiles < PP_FUSED_WGS ? ntiles : PP_FUSED_WGS;
+  hipLaunchKernelGGL(k_rgb_fused_bwd, dim3(grid), dim3(256), 0, st, params, acts, rgb, rgb_grad, count, capacity, ybar,
+                     params_grad, feat_grad, logit_grad, lg_ld);
+  const size_t LS = (size_t)capacity * 128;
+  return pp_launch_wgrad_chain(ybar, acts + LS, params_grad + RGF_W2, ybar + LS, acts, params_grad + RGF_W1, ybar + 2 * LS,
+                               feat, params_grad + RGF_W0, 64, count, 1, capacity, st);
+}
+

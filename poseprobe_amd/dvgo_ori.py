@@ -118,7 +118,7 @@ class _DVGORender(torch.autograd.Function):
                       g_depth.contiguous(), None, g_alpha, g_rgb)
         g_rgb = g_rgb * sel.bool()[:, None]
         n_gemm = model.rgbnet_kwargs['rgbnet_depth'] - 1
-        scratch = torch.empty(2 * cap * 128 + 16384, **f)
+        scratch = torch.empty(3 * cap * 128 + 16384, **f)
         pgrad = torch.zeros_like(params)
         g_feat = torch.empty(cap, ld, **f)
         g_k0raw = None if k0_raw is None else torch.zeros(cap, model.k0_dim, **f)

@@ -234,7 +234,7 @@ class RenderCore:
         if g_rgb_ext is not None:
             ws.g_rgb.add_(g_rgb_ext)
         ctx = ops.side_context() if self.use_side_stream else None
-        ops.rgbnet_bwd(rgbnet_p, ws.feat, ws.rgb_acts, ws.rgb, ws.g_rgb, ws.count, ws.cap, ws.scratch[-(2 * ws.cap * 128 + 49152):],
+        ops.rgbnet_bwd(rgbnet_p, ws.feat, ws.rgb_acts, ws.rgb, ws.g_rgb, ws.count, ws.cap, ws.scratch,
                        rgbnet_grad, ws.g_feat, ctx)
         ops.color_feat_bwd(sc, k0_cl, ws.pts, ws.viewdirs, ws.ray_id, ws.gradient, pe_w, ws.count, ws.cap, ws.g_feat,
                            k0_grad_cl, ws.g_pts, ws.g_gradient, ws.g_view_s)

@@ -58,7 +58,7 @@ f = lambda: ops.rgbnet_fwd(rgb_p, feat, count, cap, racts, rgb)
 t = timeit(f, a.iters)
 print(f'rgb_fwd   {t:8.1f} us'); res['rgb'] = rgb[:M].clone().cpu()
 g_rgb = rnd(cap, 3)
-rscr = torch.zeros(2 * cap * 128 + 49152, device=dev)
+rscr = torch.zeros(3 * cap * 128 + 49152, device=dev)
 rgrad = torch.zeros_like(rgb_p); fgrad = torch.zeros(cap, 64, device=dev)
 def rb():
     rgrad.zero_()
