@@ -52,10 +52,13 @@ __device__ __forceinline__ void load_w_cols(float4 (&w)[K / 8], const float* __r
   }
 }
 
-// acc[t] += A[t*32 + l31][:] . w   for a 64-row tile in LDS
-template <int K>
+// acc[t] += A[t*32 + l31][:] . w   for a 64-row tile in LDS.  `between(g)` is called after the MFMAs of operand group g
+// have been issued: work placed there (LDS-direct load issue, address arithmetic) executes in the shadow of the matrix
+// pipe instead of in front of it - with one wavefront per SIMD nothing else would hide it.
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+template <int K, class Hook = NoHook>
 __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float4 (&w)[K / 8], f32x16 (&acc)[2],
-                                         int l31, int lh) {
+                                         int l31, int lh, Hook between = Hook()) {
   const float* a0p = As + l31 * LDA + 4 * lh;
   const float* a1p = a0p + 32 * LDA;
   // operands of group g+1 are fetched before the MFMAs of group g (LDS latency hides behind 8 x 16 matrix passes)
@@ -77,6 +80,7 @@ __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const flo
     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, w[g].w, acc[0], 0, 0, 0);
     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, w[g].w, acc[1], 0, 0, 0);
     a0 = n0; a1 = n1;
+    between(g);
   }
 }
 
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd(const float* __restrict_
                                                         float* __restrict__ pts_grad) {
   __shared__ __attribute__((aligned(16))) float As[3][TILE_ROWS * LDA];
   __shared__ __attribute__((aligned(16))) float XS[TILE_ROWS * 128];     // X3 rows of the NEXT tile (unpadded, lane-contiguous)
-  __shared__ __attribute__((aligned(16))) float MK[8 * 256];             // ReLU gates of the current layer, one slot per lane
+  __shared__ __attribute__((aligned(16))) float MK[2][8 * 256];          // ReLU gates of the current / next layer, one slot per lane
   __shared__ __attribute__((aligned(16))) float W0s[4 * LDA];
   __shared__ __attribute__((aligned(16))) float G[2][256];               // raw out_grad of the current / next tile
   __shared__ __attribute__((aligned(16))) float Ps[2][64];               // sample positions of the current / next tile
@@ -360,38 +364,39 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd(const float* __restrict_
   // ---- LDS-direct staging of tile t into parity slot b: X3 rows -> XS, out_grad -> G[b], positions -> Ps[b].
   // Rows / samples past the end are clamped to the last valid one; their out_grad slot is zeroed after the wait, which
   // zeroes every contribution of those samples.
-  auto stage = [&](int t, int b) {
+  // piece i of 10: i < 8 two X3 rows, 8 = out_grad, 9 = positions (issued one per MFMA operand group, see mma_tile)
+  auto stage_piece = [&](int t, int b, int i) {
     const int rn0 = t * TILE_ROWS, sn0 = t * 16;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    if (i < 8) {
       const int rl = 16 * wid + 2 * i;                                   // two rows (2 x 512 B) per instruction
       const int row = min(rn0 + rl + lh, R - 1);
       __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(X3 + (size_t)row * 128 + l31 * 4), PP_LDS_PTR(&XS[rl * 128]), 16, 0, 0);
-    }
-    {
+    } else if (i == 8) {
       const int e = min(sn0 * 16 + tid, M * 16 - 1);
       __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(out_grad + e), PP_LDS_PTR(&G[b][wid * 64]), 4, 0, 0);
-    }
-    if (wid == 0) {
+    } else if (wid == 0) {
       const int e = min(sn0 * 3 + lane, M * 3 - 1);
       __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(pts + e), PP_LDS_PTR(&Ps[b][0]), 4, 0, 0);
     }
   };
-  // gates of the 8 samples a lane owns (primal rows of X): one dword per (t, q) into this lane's private MK slots
-  auto stage_masks = [&](const float* __restrict__ X, int r0) {
+  auto stage = [&](int t, int b) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = min(r0 + t * 32 + 8 * q + 4 * lh, R - 1);
-        __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(X + (size_t)row * 128 + col), PP_LDS_PTR(&MK[(t * 4 + q) * 256 + wid * 64]), 4, 0, 0);
-      }
+    for (int i = 0; i < 10; ++i) stage_piece(t, b, i);
   };
-  auto read_masks = [&](float (&mk)[2][4]) {
+  // gates of the 8 samples a lane owns (primal rows of X): one dword per (t, q) into this lane's private MK slots
+  auto stage_mask_piece = [&](const float* __restrict__ X, int r0, int mb, int i) {      // i = t*4 + q
+    const int row = min(r0 + (i >> 2) * 32 + 8 * (i & 3) + 4 * lh, R - 1);
+    __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(X + (size_t)row * 128 + col), PP_LDS_PTR(&MK[mb][i * 256 + wid * 64]), 4, 0, 0);
+  };
+  auto stage_masks = [&](const float* __restrict__ X, int r0, int mb) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stage_mask_piece(X, r0, mb, i);
+  };
+  auto read_masks = [&](float (&mk)[2][4], int mb) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) mk[t][q] = MK[(t * 4 + q) * 256 + tid];
+      for (int q = 0; q < 4; ++q) mk[t][q] = MK[mb][(t * 4 + q) * 256 + tid];
   };
   // output layer backward of the staged tile -> As[0] (+ HBM copy), weight / bias partial sums in registers
   auto out_layer_bwd = [&](int t, int b) {
@@ -410,8 +415,9 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd(const float* __restrict_
         for (int c = 0; c < 4; ++c) {
           const float4 g = *reinterpret_cast<const float4*>(&G[b][(h0 * 8 + q) * 16 + c * 4]);
           const float x = xs[(4 * q + c) * 128];
-          wacc4[0] += g.x * x; wacc4[1] += g.y * x; wacc4[2] += g.z * x; wacc4[3] += g.w * x;
-          const float yb = g.x * w4a + g.y * w4b + g.z * w4c + g.w * w4d;
+          wacc4[0] = fmaf(g.x, x, wacc4[0]); wacc4[1] = fmaf(g.y, x, wacc4[1]);
+          wacc4[2] = fmaf(g.z, x, wacc4[2]); wacc4[3] = fmaf(g.w, x, wacc4[3]);
+          const float yb = fmaf(g.w, w4d, fmaf(g.z, w4c, fmaf(g.y, w4b, g.x * w4a)));
           const float v = on ? yb : 0.f;
           if (c == 0) bacc3 += v;
           at[(4 * q + c) * LDA] = v;
@@ -427,6 +433,7 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd(const float* __restrict_
   };
 
   stage(blockIdx.x, 0);
+  stage_masks(X2, blockIdx.x * TILE_ROWS, 0);
   __builtin_amdgcn_s_waitcnt(0);        // all prologue loads landed (see k_warp_fused_fwd)
   __syncthreads();
   zero_invalid_grad(blockIdx.x, 0);
@@ -438,31 +445,38 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd(const float* __restrict_
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
     const int r0 = tile * TILE_ROWS, s0 = tile * 16;
     const int tnext = tile + gridDim.x;
-    if (tnext < ntiles) stage(tnext, par ^ 1);       // consumed at the bottom of this iteration, 3 MFMA blocks later
-    stage_masks(X2, r0);
     float mk[2][4];
     f32x16 acc[2];
+    // All global reads of the loop are LDS-direct loads issued from INSIDE the MFMA loops (one or two per operand group),
+    // one block ahead of their use.  Gate buffers alternate: this tile's X2 gates sit in MK[par]; X1 -> MK[par^1] during
+    // block 3; X0 -> MK[par] during block 2 (after its X2 content was consumed); the next tile's X2 -> MK[par^1]
+    // during block 1.
     // ---- layer 3: Ybar2 = gate(X2) . (Ybar3 W3)
     zero_acc(acc);
-    mma_tile<128>(As[0], w3, acc, l31, lh);
+    mma_tile<128>(As[0], w3, acc, l31, lh, [&](int g) {
+      if (g < 8) stage_mask_piece(X1, r0, par ^ 1, g);
+      if (g < 10 && tnext < ntiles) stage_piece(tnext, par ^ 1, g);
+    });
     PP_WAIT_VMEM();
-    read_masks(mk);
+    read_masks(mk, par);
     mask_epilogue<true>(acc, mk, r0, R, col, lh, ybar + LS, As[1], bacc2);
-    stage_masks(X1, r0);                             // (each lane overwrites only its own, already consumed, slots)
     __syncthreads();
     // ---- layer 2
     zero_acc(acc);
-    mma_tile<128>(As[1], w2, acc, l31, lh);
-    PP_WAIT_VMEM();
-    read_masks(mk);
+    mma_tile<128>(As[1], w2, acc, l31, lh, [&](int g) {
+      if (g < 8) stage_mask_piece(X0, r0, par, g);
+    });
+    PP_WAIT_VMEM();                                  // also: XS / G / Ps of the next tile have landed
+    read_masks(mk, par ^ 1);
     mask_epilogue<true>(acc, mk, r0, R, col, lh, ybar + 2 * LS, As[2], bacc1);
-    stage_masks(X0, r0);
     __syncthreads();
-    // ---- layer 1: Ybar0 stays in LDS
+    // ---- layer 1: Ybar0 stays in LDS (the next tile's X2 gates ride in this block)
     zero_acc(acc);
-    mma_tile<128>(As[2], w1, acc, l31, lh);
-    PP_WAIT_VMEM();                                  // also covers stage(tnext): XS / G / Ps of the next tile have landed
-    read_masks(mk);
+    mma_tile<128>(As[2], w1, acc, l31, lh, [&](int g) {
+      if (g < 8 && tnext < ntiles) stage_mask_piece(X2, tnext * TILE_ROWS, par ^ 1, g);
+    });
+    PP_WAIT_VMEM();
+    read_masks(mk, par);
     mask_epilogue<false>(acc, mk, r0, R, col, lh, ybar, As[1], bdummy);
     __syncthreads();
     // ---- layer 0: W0bar[j][i] += Ybar0[4s][j] p_i + Ybar0[4s+1+i][j], b0bar[j] += Ybar0[4s][j]  (thread = feature j)
@@ -504,10 +518,11 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd(const float* __restrict_
       const int s = tid >> 2, i = tid & 3;
       if (i < 3 && s0 + s < M) {
         const float v = (Red[tid] + Red[64 + tid]) + (Red[128 + tid] + Red[192 + tid]);
-        pts_grad[(s0 + s) * 3 + i] += v;
+        atomicAdd(&pts_grad[(s0 + s) * 3 + i], v);   // no load to wait for (a read-modify-write would drain the stores)
       }
     }
-    // ---- the next tile's output-layer backward into As[0] (last read by this tile's first MFMA block)
+    // ---- the next tile's output-layer backward into As[0] (last read by this tile's first MFMA block).  Measured: issuing
+    // it from inside the last MFMA loop instead is slower (its LDS round trips stall the MFMA issue of the lone wave).
     if (tnext < ntiles) out_layer_bwd(tnext, par ^ 1);
     __syncthreads();
   }
