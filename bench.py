@@ -89,6 +89,12 @@ def main():
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON record).  Libraries that print to fd 1 (RCCL prints a version banner when
+    # a communicator is created) are sent to stderr for the duration of the run.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -116,8 +122,9 @@ def main():
 
     # every step's randomness is generated up front and is resident on the device: rank r takes its own ray shard
     total = args.steps + args.warmup
+    extra = min(10, args.steps)          # untimed post-pass that prices the MLP chains (second, informative roofline)
     idx_all, jit_all = [], []
-    for s in range(total):
+    for s in range(total + extra):
         idx, jit = syn.step_randomness(V * H * W, N * world, seed=2000 + s)
         idx_all.append(idx[rank::world])
         jit_all.append(jit[rank::world])
@@ -142,7 +149,8 @@ def main():
         ev.append((e0, e1))
 
     ops.grid_tv_adam_step = timed_grid_step
-    # second roofline: the two MLPs on the matrix cores (fp32 MFMA), timed the same way
+    # second roofline: the two MLPs on the matrix cores (fp32 MFMA).  Every event pair drains the launch pipeline, so
+    # these four extra pairs per step are taken in a short pass AFTER the timed region, not inside it.
     mlp_ev = []
 
     def timed(fn):
@@ -154,15 +162,11 @@ def main():
             mlp_ev.append((e0, e1))
         return wrapper
 
-    for name in ('warp_fwd', 'warp_bwd', 'rgbnet_fwd', 'rgbnet_bwd'):
-        setattr(ops, name, timed(getattr(ops, name)))
-
     gs = 10
     for s in range(args.warmup):
         eng.train_step(idx_all[s], jit_all[s], gs + s)
     barrier()
     ev.clear()
-    mlp_ev.clear()
     t0 = time.perf_counter()
     for s in range(args.warmup, total):
         eng.train_step(idx_all[s], jit_all[s], gs + s)
@@ -173,6 +177,17 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     M = int(eng.ws.count.item())
+    mlp_names = ('warp_fwd', 'warp_bwd', 'rgbnet_fwd', 'rgbnet_bwd')
+    mlp_orig = {n: getattr(ops, n) for n in mlp_names}
+    for n in mlp_names:
+        setattr(ops, n, timed(mlp_orig[n]))
+    n_ev = len(ev)
+    for s in range(total, total + extra):
+        eng.train_step(idx_all[s], jit_all[s], gs + s)
+    barrier()
+    for n in mlp_names:
+        setattr(ops, n, mlp_orig[n])
+    del ev[n_ev:]                                    # the grid kernel is priced over the timed region only
     grid_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float('nan')
     xb, xe = eng.x_slab
     X, Y, Z = cfg.world_size
@@ -181,7 +196,7 @@ def main():
     # MFMA-shaped work per sample: warp hidden GEMMs 3 layers x 4 rows x 2*128*128 x (fwd + 2 bwd),
     # rgbnet (64*128 + 2*128*128) x 2 x (fwd + 2 bwd)
     flop_per_sample = 3 * (3 * 4 * 2 * 128 * 128) + 3 * (2 * (64 * 128 + 2 * 128 * 128))
-    mlp_ms = float(np.sum([a.elapsed_time(b) for a, b in mlp_ev])) / max(args.steps, 1) if mlp_ev else float('nan')
+    mlp_ms = float(np.sum([a.elapsed_time(b) for a, b in mlp_ev])) / max(extra, 1) if mlp_ev else float('nan')
     mlp_tflops = flop_per_sample * M / (mlp_ms * 1e-3) / 1e12
 
     if rank == 0:
@@ -192,11 +207,11 @@ def main():
             'config': {'workload': f'DTU-scan1-like {V}-view {H}x{W}, object-branch train step (ray select, render, '
                                    f'losses, backward, TV+Adam), {G}^3 grid, {cfg.n_samples} samples/ray, '
                                    f'N_rand={N}/GPU', 'grid': G, 'n_rand_per_gpu': N, 'samples_in_bbox_last_step': M,
-                       'parallelism': f'ray-sharded dp{world}, ZeRO-1 grid optimiser' if world > 1 else 'single GPU'},
+                       'parallelism': (f'ray-sharded dp{world}, k0 gradient exchanged per sample (all-gather), replicated grid optimiser' if (dctx is None or dctx.mode == 'samples') else f'ray-sharded dp{world}, dense reduce-scatter + ZeRO-1 grid optimiser') if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'kernel': 'k_grid_tv_adam (fused TV-grad + Adam + zero-grad over k0)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': pmc_traffic(G, (xe - xb) * Y * Z), 'ms_per_launch': grid_ms, 'algorithmic_bytes_per_launch': grid_bytes},
-            'roofline_mfma': {'bound': 'mfma', 'kernel': 'warp + rgbnet MLP chains (k_gemm128 / k_gemm_tn, fp32 MFMA 32x32x2)',
+            'roofline_mfma': {'bound': 'mfma', 'kernel': 'warp + rgbnet MLP chains (layer-fused fwd / bwd-data / weight-gradient kernels, fp32 MFMA 32x32x2)',
                               'achieved': mlp_tflops, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': mlp_tflops / 157.3,
                               'ms_per_step': mlp_ms, 'flop_per_sample': flop_per_sample},
         }
@@ -204,7 +219,8 @@ def main():
             out['cpu_baseline'] = cpu_baseline(G, H, W, V, N, views, args.cpu_budget)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if use_dist:
         torch.distributed.destroy_process_group()
 

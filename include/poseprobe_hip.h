@@ -148,6 +148,17 @@ int pp_geometry_bwd(const pp_scene* sc, const float* sdf_grid, const float* sdf_
                     const float* g_correction, int32_t accumulate, float* warp_out_grad, float* pts_grad,
                     float* viewdir_grad_s, float* sdf_ab_grad, void* stream);
 
+/* ---------------------------------------------------------------- multi-GPU: k0 gradient exchange at sample granularity
+ * (no counterpart in the reference, which has no distributed path; replaces a dense 196 MB reduce-scatter by an
+ * all-gather of 64 B per sample).  pp_k0_pack_samples writes packed[capacity][16] = { feat_grad[:, :k0_dim] (12 slots),
+ * pts xyz, pad } and the sample count (int32 bit pattern) into packed[0][15]; pp_k0_scatter_packed replays the trilinear
+ * scatter of pp_color_feat_bwd for n_shards such buffers laid out back to back ([n_shards][capacity][16]) into
+ * k0_grad_cl (atomic +=).  Pass k0_grad_cl = NULL to pp_color_feat_bwd to skip its own scatter. */
+int pp_k0_pack_samples(const float* pts, const float* feat_grad, const int32_t* count, int32_t capacity, int32_t k0_dim,
+                       float* packed, void* stream);
+int pp_k0_scatter_packed(const pp_scene* sc, const float* packed, int32_t n_shards, int32_t capacity, float* k0_grad_cl,
+                         void* stream);
+
 /* ---------------------------------------------------------------- colour features: DenseGrid.forward for k0
  * (lib/grid.py:47-58, zeros padding), BARF positional encoding of xyz and view (voxurf_coarse.py:721-732,
  * :1009-1025), normal (:1028-1030) -> feat[M,64] (57 used, zero padded).  k0 is stored channels-last

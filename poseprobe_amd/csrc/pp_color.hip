@@ -220,6 +220,68 @@ __global__ __launch_bounds__(256) void k_k0_scatter(SceneDev sc, const float* __
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Multi-GPU exchange of the k0 gradient at SAMPLE granularity.  The dense gradient of a 160^3 x 12 grid is 196 MB, yet a
+// rank's rays touch it through ~55 k samples only; what travels is therefore the scatter's INPUT, 64 bytes per sample:
+// packed[m] = { d loss / d k0-feature [12], pts xyz [3], pad }, with the rank's sample count stored in packed[0][15]
+// (bit pattern of an int32).  After one all-gather every rank replays the scatter for all shards into its own full
+// gradient grid.  DESIGN.md 7.
+// ------------------------------------------------------------------------------------------------------------------
+#define PP_PACK_LD 16
+__global__ __launch_bounds__(256) void k_k0_pack(const float* __restrict__ pts, const float* __restrict__ feat_grad,
+                                                 const int32_t* __restrict__ count, int capacity, int C,
+                                                 float* __restrict__ packed) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int m = t >> 4, ch = t & 15;
+  int M = min(count[0], capacity);
+  if (t == 15) packed[15] = __int_as_float(M);          // row 0, pad slot: this shard's sample count
+  if (m >= M) return;
+  float v = 0.f;
+  if (ch < C) v = feat_grad[(size_t)m * PP_FEAT_LD + ch];
+  else if (ch >= 12 && ch < 15) v = pts[m * 3 + (ch - 12)];
+  if (!(m == 0 && ch == 15)) packed[(size_t)m * PP_PACK_LD + ch] = v;
+}
+
+__global__ __launch_bounds__(256) void k_k0_scatter_packed(SceneDev sc, const float* __restrict__ packed, int capacity,
+                                                           float* __restrict__ k0_grad) {
+  const float* __restrict__ shard = packed + (size_t)blockIdx.y * capacity * PP_PACK_LD;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int m = t >> 4, ch = t & 15;
+  int M = min(__float_as_int(shard[15]), capacity);
+  if (m >= M || ch >= sc.C) return;
+  const float* row = shard + (size_t)m * PP_PACK_LD;
+  float p[3] = {row[12], row[13], row[14]};
+  K0Tri tr;
+  k0_setup(sc, p, tr);
+  float g = row[ch];
+  if (g == 0.f) return;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    size_t off; float w;
+    if (k0_corner(sc, tr, c, off, w)) atomicAdd(&k0_grad[off + ch], w * g);
+  }
+}
+
+extern "C" int pp_k0_pack_samples(const float* pts, const float* feat_grad, const int32_t* count, int32_t capacity,
+                                  int32_t k0_dim, float* packed, void* stream) {
+  PP_REQUIRE(pts && feat_grad && count && packed, "null pointer");
+  PP_REQUIRE(capacity > 0 && k0_dim > 0 && k0_dim <= 12, "bad sizes");
+  hipLaunchKernelGGL(k_k0_pack, dim3(pp_div_up(capacity * 16, 256)), dim3(256), 0, pp_stream(stream), pts, feat_grad, count,
+                     capacity, k0_dim, packed);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_k0_scatter_packed(const pp_scene* sc, const float* packed, int32_t n_shards, int32_t capacity,
+                                    float* k0_grad_cl, void* stream) {
+  PP_REQUIRE(sc && packed && k0_grad_cl, "null pointer");
+  PP_REQUIRE(capacity > 0 && n_shards > 0 && n_shards <= 65535 && sc->k0_dim <= 12, "bad sizes");
+  hipLaunchKernelGGL(k_k0_scatter_packed, dim3(pp_div_up(capacity * 16, 256), n_shards), dim3(256), 0, pp_stream(stream),
+                     pp_scene_dev(sc), packed, capacity, k0_grad_cl);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Generic feature builder (DirectVoxGO twin, lib/dvgo_ori.py:336-352): [k0 (C - k0_skip channels) | xyz, sin, cos |
 // view, sin, cos | optional normal] with runtime widths, un-weighted encodings when pe_w == NULL, row stride `ld`.
 // `sel[M]` (uint8, optional) marks the samples that take part (weights > fast_color_thres); others get zero rows.

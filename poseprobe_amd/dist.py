@@ -2,16 +2,28 @@
 xGMI via torch.distributed (backend "nccl" == RCCL on ROCm).
 
 The reference has no distributed path on the live loop; this module introduces the one exchange
-step the path needs, shaped for MI355X's point-to-point xGMI fabric:
+step the path needs, shaped for MI355X's point-to-point xGMI fabric (a ring collective is bound by ONE ~50-64 GB/s
+link at W=2 and by a few links at W=8, so bytes on the wire are what matters).  Two modes:
 
+mode "samples" (default) - exchange the k0 gradient at SAMPLE granularity
+  * a rank's rays reach the dense 196 MB gradient grid through ~55 k samples only, so what travels is the INPUT of the
+    scatter: 64 B per sample (12 feature gradients + position), one all-gather of [capacity, 16] floats per rank
+    (12 MB) instead of a 196 MB reduce-scatter plus a 196 MB all-gather; it overlaps the geometry / warp backward,
+  * every rank replays the scatter for all shards (15 us each) and runs the full fused TV+Adam pass (replicated),
+  * no parameter all-gather.  Float atomics make the replicas differ in the last bit, so every `resync_every` steps
+    rank 0 broadcasts grid + moments (amortised to ~20 us / step).
+
+mode "zero1" (PP_DIST_MODE=zero1) - dense exchange with a sharded optimiser
   * dense k0 gradient  : reduce-scatter along X (each rank receives the sum of its own x-slab only),
   * optimiser          : ZeRO-1 - each rank runs the fused TV+Adam kernel on its slab (1/W of the dense traffic),
-  * parameters         : all-gather of the updated slabs,
-  * everything small   : ONE all-reduce bucket (MLPs + sdf alpha/beta + 6-DoF pose grads, ~370 KB).
+  * parameters         : all-gather of the updated slabs (bit-identical replicas by construction).
 
-The TV term is rank invariant (a function of the replicated parameters) and is therefore added inside the sharded
-optimiser kernel, never reduced.  Gradients are averaged (sum * 1/W), i.e. the global batch is W * N_rand rays.
+Both: everything small goes through ONE all-reduce bucket (MLPs + sdf alpha/beta + 6-DoF pose grads, ~370 KB); the
+TV term is rank invariant (a function of the replicated parameters) and is added inside the optimiser kernel, never
+reduced; gradients are averaged (sum * 1/W), i.e. the global batch is W * N_rand rays.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -23,12 +35,17 @@ def slab_bounds(X, world, rank):
 
 
 class DistContext:
-    def __init__(self, group=None):
+    def __init__(self, group=None, mode=None, resync_every=256):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.backend = dist.get_backend(group)
         self._bucket = None
+        self.mode = mode or os.environ.get('PP_DIST_MODE', 'samples')
+        assert self.mode in ('samples', 'zero1')
+        self.resync_every = resync_every
+        self._gathered = None
+        self._steps = 0
 
     # ---- generic tensor-level collectives (also exercised on CPU with gloo) ---------------------------------
     def shardable(self, X):
@@ -76,10 +93,40 @@ class DistContext:
             t.copy_(self._bucket[o:o + t.numel()].view_as(t))
             o += t.numel()
 
-    # ---- hooks used by engine.TrainEngine (overlap of the two big collectives with compute) -------------------
+    def all_gather_rows(self, local, out=None, async_op=False):
+        """local [rows, ld] -> out [W, rows, ld] (every rank's buffer, rank order).  Returns (out, work)."""
+        if out is None:
+            out = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        if self.backend == 'gloo':
+            parts = [out[r] for r in range(self.world)]
+            work = dist.all_gather(parts, local.contiguous(), group=self.group, async_op=async_op)
+        else:
+            work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=async_op)
+        return out, work
+
+    def broadcast_state(self, tensors, src=0):
+        for t in tensors:
+            dist.broadcast(t, src=src, group=self.group)
+
+    # ---- hooks used by engine.TrainEngine (overlap of the big collectives with compute) ---------------------------
+    @property
+    def local_scatter(self):
+        """False: the engine must not scatter its own samples into k0_grad (mode "samples" replays all shards later)."""
+        return self.mode != 'samples'
+
     def start_grid_reduce(self, eng):
-        """Called right after the k0 scatter kernel: the dense reduce-scatter (async, RCCL stream) overlaps the
-        geometry / warp-MLP backward, which does not touch the grid gradient."""
+        """Called right after the colour-feature backward.  "samples": pack this rank's scatter input and start the
+        async all-gather; "zero1": start the dense reduce-scatter.  Either overlaps the geometry / warp-MLP backward,
+        which does not touch the grid gradient."""
+        if self.mode == 'samples':
+            from . import ops
+            ws = eng.ws
+            if getattr(ws, 'k0_packed', None) is None:
+                ws.k0_packed = torch.zeros(ws.cap, 16, dtype=torch.float32, device=ws.pts.device)
+                self._gathered = torch.zeros(self.world, ws.cap, 16, dtype=torch.float32, device=ws.pts.device)
+            ops.k0_pack_samples(ws.pts, ws.g_feat, ws.count, ws.cap, eng.cfg.k0_dim, ws.k0_packed)
+            _, self._grid_work = self.all_gather_rows(ws.k0_packed, self._gathered, async_op=True)
+            return
         X = eng.k0_grad.shape[0]
         if self.shardable(X) and self.backend != 'gloo':
             xb, xe = slab_bounds(X, self.world, self.rank)
@@ -90,6 +137,15 @@ class DistContext:
 
     def reduce_gradients(self, eng):
         X = eng.k0_grad.shape[0]
+        if self.mode == 'samples':
+            from . import ops
+            self._grid_work.wait()
+            self._grid_work = None
+            ops.k0_scatter_packed(eng.cfg.pp, self._gathered, self.world, eng.ws.cap, eng.k0_grad)
+            eng.x_slab = (0, X)
+            self.all_reduce_small([eng.flat.grad, eng.se3_grad])
+            eng.grad_scale = 1.0 / self.world
+            return
         work = getattr(self, '_grid_work', None)
         if work is None:
             self.start_grid_reduce(eng)
@@ -112,6 +168,11 @@ class DistContext:
         """Async all-gather of the updated slabs; the next step waits for it only right before its first k0 lookup."""
         X = eng.k0_grad.shape[0]
         self._param_work = None
+        if self.mode == 'samples':
+            self._steps += 1
+            if self.resync_every and self._steps % self.resync_every == 0:
+                self.broadcast_state([eng.k0_cl, eng.k0_m, eng.k0_v])    # replicas differ in the last bit (float atomics)
+            return
         if self.shardable(X):
             if self.backend == 'gloo':
                 self.all_gather_grid(eng.k0_cl)

@@ -365,8 +365,10 @@ class TrainEngine:
             ops.loss_samples(w.gradient, w.grad_deform, w.warp_out, w.sdf_deform, w.count, w.cap, 1.0, w_dyn, ls,
                              w.g_gradient, w.g_grad_deform, w.g_corr, w.g_sdf_deform, w.loss_out)
 
+        # multi-GPU "samples" mode: no local k0 scatter, the gathered scatter inputs of all ranks are replayed later
+        k0_grad = self.k0_grad if (self.dist is None or self.dist.local_scatter) else None
         self.core.backward(ws, self.k0_cl, self.sdf, P.view('sdf_ab'), P.view('rgbnet'), P.view('warp'), inv_s, self.pe_w,
-                           self.k0_grad, P.view('sdf_ab', 'grad'), P.view('rgbnet', 'grad'), P.view('warp', 'grad'),
+                           k0_grad, P.view('sdf_ab', 'grad'), P.view('rgbnet', 'grad'), P.view('warp', 'grad'),
                            g_gradient_ext=add_sample_losses, g_sdf_deform=ws.g_sdf_deform,
                            g_grad_deform=ws.g_grad_deform, g_correction=ws.g_corr,
                            after_k0_grad=None if self.dist is None else (lambda: self.dist.start_grid_reduce(self)))

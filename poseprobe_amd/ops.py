@@ -155,6 +155,14 @@ def color_feat_bwd(sc, k0_cl, pts, viewdirs, ray_id, gradient, pe_w, count, capa
               _f(vgrad_s), _stream())
 
 
+def k0_pack_samples(pts, feat_grad, count, capacity, k0_dim, packed):
+    _lib.call('pp_k0_pack_samples', _f(pts), _f(feat_grad), _i(count), capacity, int(k0_dim), _f(packed), _stream())
+
+
+def k0_scatter_packed(sc, packed, n_shards, capacity, k0_grad_cl):
+    _lib.call('pp_k0_scatter_packed', ctypes.byref(sc), _f(packed), int(n_shards), capacity, _f(k0_grad_cl), _stream())
+
+
 # ------------------------------------------------------------------------------------------- MLPs
 def rgbnet_fwd(params, feat, count, capacity, acts, rgb):
     _lib.call('pp_rgbnet_fwd', _f(params), _f(feat), _i(count), capacity, _f(acts), _f(rgb), _stream())

@@ -87,6 +87,67 @@ def test_sharded_step_equals_single_process(X):
     assert q.get(timeout=5) is True
 
 
+def _worker_samples(rank, world, port, q):
+    """mode "samples": every rank contributes a packed [cap,16] buffer (count in row 0, slot 15); after ONE all-gather
+    each rank replays all shards into a dense gradient.  The replay here is a CPU stand-in (nearest-voxel deposit) for
+    pp_k0_scatter_packed; what is under test is the collective and the count-in-band convention."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from poseprobe_amd.dist import DistContext
+    ctx = DistContext(mode='samples')
+    assert not ctx.local_scatter
+    cap, G, C = 64, 6, 12
+    g = torch.Generator().manual_seed(11 + rank)
+    M = 20 + 7 * rank                                            # ragged: a different sample count per rank
+    packed = torch.zeros(cap, 16)
+    packed[:M, :C] = torch.randn(M, C, generator=g)
+    packed[:M, 12:15] = torch.rand(M, 3, generator=g)            # positions in [0,1)^3
+    packed[M:, :15] = 99.0                                        # stale rows past the count must be ignored
+    packed[0, 15] = torch.tensor([M], dtype=torch.int32).view(torch.float32)[0]
+
+    def replay(shards):
+        grad = torch.zeros(G * G * G, C)
+        for sh in shards:
+            m = int(sh[0, 15:16].view(torch.int32)[0])
+            ijk = (sh[:m, 12:15] * G).long().clamp_(0, G - 1)
+            lin = (ijk[:, 0] * G + ijk[:, 1]) * G + ijk[:, 2]
+            grad.index_add_(0, lin, sh[:m, :C])
+        return grad
+
+    out, _ = ctx.all_gather_rows(packed)
+    assert out.shape == (world, cap, 16)
+    mine = replay(out)
+    allp = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(allp, packed)
+    ref = replay(allp)
+    gs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gs, mine)
+    ok = torch.equal(mine, ref) and all(torch.equal(gs[0], x) for x in gs)
+    counts = [int(out[r, 0, 15:16].view(torch.int32)[0]) for r in range(world)]
+    ok = ok and counts == [20 + 7 * r for r in range(world)]
+    # periodic resync primitive
+    t = torch.full((4,), float(rank))
+    ctx.broadcast_state([t])
+    ok = ok and bool((t == 0).all())
+    if rank == 0:
+        q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+def test_sample_exchange_equals_single_process():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_samples, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_slab_bounds_cover_grid():
     from poseprobe_amd.dist import slab_bounds
     for X, W in ((160, 8), (96, 4), (8, 2)):

@@ -109,3 +109,36 @@ def test_trajectory_3_steps_matches_oracle():
     W1 = unpack_rgbnet(rg)[1][0]
     dev = np.abs(c(W1) - c(P['rgbnet'][1][0]))
     assert (dev > 1e-4).mean() < 0.02, 'rgbnet layer-1 weights deviate after 3 steps'
+
+
+@pytest.mark.parametrize('mode', ['samples', 'zero1'])
+def test_dist_modes_on_one_rank_match_plain_engine(mode):
+    """Both multi-GPU choreographies (poseprobe_amd.dist) run through RCCL with world_size 1 and must reproduce the plain
+    single-GPU step: 'samples' = pack -> all-gather -> replayed scatter, 'zero1' = reduce-scatter -> slab Adam ->
+    all-gather.  (The N>1 arithmetic is covered on CPU by tests/test_dist_gloo.py.)"""
+    import os
+    import socket
+    import torch.distributed as dist
+    from poseprobe_amd import synthetic as syn
+    from poseprobe_amd.dist import DistContext
+    if not dist.is_initialized():
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    d = load('forward_g8_s10.npz')
+    plain, _ = build_engine(d, pose_iters=1000)
+    sharded, _ = build_engine(d, pose_iters=1000, dist_ctx=DistContext(mode=mode, resync_every=2))
+    V, H, W = d['images'].shape[:3]
+    for eng in (plain, sharded):
+        eng.zero_grads()
+        for s in range(3):
+            idx, jit = syn.step_randomness(V * H * W, int(d['n_rand']), seed=40 + s)
+            eng.train_step(torch.tensor(idx, dtype=torch.int32, device='cuda'), torch.tensor(jit, device='cuda'), 10 + s)
+    torch.cuda.synchronize()
+    c = lambda t: t.detach().cpu().numpy()
+    # float atomics in the scatter are unordered, Adam's first steps amplify rounding-level gradient differences: same
+    # budget as the oracle trajectory test
+    a, b = c(sharded.k0_cl), c(plain.k0_cl)
+    assert (np.abs(a - b) > 1e-4).mean() < 0.02
+    assert_close(c(sharded.se3), c(plain.se3), rtol=0, atol=2e-4, name=f'se3 ({mode})')
+    assert (np.abs(c(sharded.flat.data) - c(plain.flat.data)) > 1e-4).mean() < 0.02
