@@ -1,0 +1,134 @@
+"""The two MLP chains (pp_warp_fwd/bwd, pp_rgbnet_fwd/bwd) against a plain PyTorch fp32 restatement (autograd for the
+backward), at sizes that exercise every tile-boundary case of the layer-fused kernels: empty input, one sample, one short
+of / exactly / one past a 16-sample (warp) and 64-row (rgbnet) tile, a capacity that is not a multiple of the tile, and
+enough tiles for several persistent iterations per work-group.
+
+Tolerances (fp32, different summation order than torch): values rtol 1e-4 / atol 1e-5; gradients 1e-3 of the tensor's max.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+OUT_RANGE = 0.7619
+
+
+def _warp_params(seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(128, 3), (128, 128), (128, 128), (128, 128), (4, 128)]
+    layers = []
+    for i, (o, k) in enumerate(shapes):
+        W = torch.randn(o, k, generator=g) * (1.0 / np.sqrt(k)) * (0.3 if i == 4 else 1.4)
+        b = torch.randn(o, generator=g) * 0.1
+        layers.append((W, b))
+    return layers
+
+
+def _warp_ref(layers, pts):
+    """4-row form in torch: row 0 = primal, rows 1..3 = d/dp_i; ReLU mask of row 0 applied to all rows (tests/analytic_model.py
+    derives it from the reference's autograd.grad passes)."""
+    (W0, b0) = layers[0]
+    y0 = pts @ W0.T + b0
+    m = (y0 > 0).float()
+    X = torch.stack([y0 * m, m * W0[:, 0], m * W0[:, 1], m * W0[:, 2]], dim=1)          # [M,4,128]
+    for W, b in layers[1:4]:
+        Y = X @ W.T
+        Y = torch.cat([Y[:, :1] + b, Y[:, 1:]], dim=1)
+        X = Y * (Y[:, :1] > 0).float()
+    W4, b4 = layers[4]
+    out = X @ W4.T
+    out = torch.cat([out[:, :1] + b4, out[:, 1:]], dim=1)
+    return out * OUT_RANGE                                                                # [M,4,4]
+
+
+def _pack(layers):
+    return torch.cat([t.reshape(-1) for W, b in layers for t in (W, b)])
+
+
+@pytest.mark.parametrize('M,cap', [(0, 40), (1, 1), (15, 15), (16, 16), (17, 40), (63, 100), (65, 65), (1000, 1003),
+                                   (9001, 9100)])
+def test_warp_chain_matches_torch(M, cap):
+    from poseprobe_amd import ops
+    dev = 'cuda'
+    layers = _warp_params(3)
+    g = torch.Generator().manual_seed(M + 1)
+    pts_h = torch.randn(cap, 3, generator=g) * 0.5
+    og_h = torch.randn(cap, 16, generator=g)
+    P = _pack(layers)
+    params = torch.zeros(P.numel() + 60, device=dev); params[:P.numel()] = P.to(dev)
+    pts, og = pts_h.to(dev), og_h.to(dev)
+    count = torch.tensor([M], dtype=torch.int32, device=dev)
+    acts = torch.full((4 * cap * 4 * 128,), float('nan'), device=dev)
+    out = torch.full((cap, 16), 7.0, device=dev)
+    ops.warp_fwd(params, pts, count, cap, OUT_RANGE, acts, out)
+    scratch = torch.zeros(3 * cap * 4 * 128 + 49152, device=dev)
+    pgrad = torch.zeros_like(params)
+    ptsg = torch.full((cap, 3), 0.25, device=dev)                      # pts_grad accumulates (+=)
+    ops.warp_bwd(params, pts, acts, og, count, cap, OUT_RANGE, scratch, pgrad, ptsg)
+    torch.cuda.synchronize()
+    assert float((out[M:] - 7.0).abs().max()) == 0 if M < cap else True          # rows past the count are not written
+    assert float((ptsg[M:] - 0.25).abs().max()) == 0 if M < cap else True
+    if M == 0:
+        assert float(pgrad.abs().max()) == 0
+        return
+    lay = [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in layers]
+    p = pts_h[:M].clone().requires_grad_(True)
+    ref = _warp_ref(lay, p)
+    (ref.reshape(M, 16) * og_h[:M]).sum().backward()
+    c = lambda t: t.detach().cpu().numpy()
+    assert_close(c(out[:M]), c(ref.reshape(M, 16)), rtol=1e-4, atol=1e-5, name='warp out')
+    assert_close(c(ptsg[:M]) - 0.25, c(p.grad), rtol=1e-3, atol=2e-5, name='warp pts_grad', scaled=1e-3)
+    gref = torch.cat([t.grad.reshape(-1) for W, b in lay for t in (W, b)])
+    assert_close(c(pgrad[:gref.numel()]), c(gref), rtol=1e-3, atol=2e-5, name='warp param grads', scaled=1e-3)
+
+
+def _rgb_params(seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(128, 57), (128, 128), (128, 128), (3, 128)]
+    return [(torch.randn(o, k, generator=g) * (1.4 / np.sqrt(k)), torch.randn(o, generator=g) * 0.1) for o, k in shapes]
+
+
+@pytest.mark.parametrize('M,cap', [(0, 70), (1, 1), (63, 63), (64, 64), (65, 130), (1000, 1003), (20000, 20011)])
+def test_rgbnet_chain_matches_torch(M, cap):
+    from poseprobe_amd import ops
+    from poseprobe_amd.engine import pack_rgbnet
+    dev = 'cuda'
+    layers = _rgb_params(5)
+    g = torch.Generator().manual_seed(M + 2)
+    feat_h = torch.zeros(cap, 64); feat_h[:, :57] = torch.randn(cap, 57, generator=g)
+    gr_h = torch.randn(cap, 3, generator=g)
+    P = pack_rgbnet(layers)
+    params = torch.zeros(P.numel() + 60, device=dev); params[:P.numel()] = P.to(dev)
+    feat, gr = feat_h.to(dev), gr_h.to(dev)
+    count = torch.tensor([M], dtype=torch.int32, device=dev)
+    acts = torch.full((3 * cap * 128,), float('nan'), device=dev)
+    rgb = torch.full((cap, 3), 7.0, device=dev)
+    ops.rgbnet_fwd(params, feat, count, cap, acts, rgb)
+    scratch = torch.zeros(3 * cap * 128 + 49152, device=dev)
+    pgrad = torch.zeros_like(params)
+    fgrad = torch.full((cap, 64), 5.0, device=dev)                     # feat_grad is assigned (=) for rows < M
+    ops.rgbnet_bwd(params, feat, acts, rgb, gr, count, cap, scratch, pgrad, fgrad)
+    torch.cuda.synchronize()
+    if M < cap:
+        assert float((rgb[M:] - 7.0).abs().max()) == 0 and float((fgrad[M:] - 5.0).abs().max()) == 0
+    if M == 0:
+        assert float(pgrad.abs().max()) == 0
+        return
+    lay = [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in layers]
+    x = feat_h[:M, :57].clone().requires_grad_(True)
+    h = x
+    for W, b in lay[:3]:
+        h = torch.relu(h @ W.T + b)
+    ref = torch.sigmoid(h @ lay[3][0].T + lay[3][1])
+    (ref * gr_h[:M]).sum().backward()
+    c = lambda t: t.detach().cpu().numpy()
+    assert_close(c(rgb[:M]), c(ref), rtol=1e-4, atol=1e-5, name='rgb')
+    assert_close(c(fgrad[:M, :57]), c(x.grad), rtol=1e-3, atol=2e-6, name='rgb feat_grad', scaled=1e-3)
+    from poseprobe_amd.engine import unpack_rgbnet
+    for i, ((gW, gb), (W, b)) in enumerate(zip(unpack_rgbnet(pgrad), lay)):
+        assert_close(c(gW), c(W.grad), rtol=1e-3, atol=2e-5, name=f'rgb W{i} grad', scaled=1e-3)
+        assert_close(c(gb), c(b.grad), rtol=1e-3, atol=2e-5, name=f'rgb b{i} grad', scaled=1e-3)
+    # the zero padding of the 57 -> 64 input columns receives no gradient from real data (features there are zero)
+    assert float(pgrad[:128 * 64].view(128, 64)[:, 57:].abs().max()) == 0
