@@ -178,6 +178,11 @@ int pp_color_feat_bwd(const pp_scene* sc, const float* k0_cl, const float* pts, 
  * (fork / join are event edges: the sequence stays hipGraph-capturable).  NULL = strictly sequential on `stream`. */
 int pp_context_create(void** ctx);
 int pp_context_destroy(void* ctx);
+/* Layer-fused chains (Voxurf shapes): with a context the weight-gradient kernel of pp_rgbnet_bwd / pp_mlp_bwd / pp_warp_bwd
+ * is launched on the auxiliary stream and NOT joined before the call returns, so that the caller's next (small) kernels
+ * run beside it.  Call pp_context_join before `scratch` is reused, before params_grad is read, and at most 4 forks
+ * apart: it makes `stream` wait for every deferred launch issued so far. */
+int pp_context_join(void* ctx, void* stream);
 
 /* ---------------------------------------------------------------- MLPs on the matrix cores (fp32 MFMA).
  * rgbnet (voxurf_coarse.py:208-216, :1032-1033): 64(57)->128->128->128->3, sigmoid.

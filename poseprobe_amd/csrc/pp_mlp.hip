@@ -487,6 +487,8 @@ static const int TN_WGS = 448;
 struct PPContext {
   hipStream_t aux;
   hipEvent_t fork[16], join[16];
+  int pending;                      // deferred side launches of the fused paths not yet joined (pp_context_join)
+  hipEvent_t dfork[4], djoin[4];
 };
 
 extern "C" int pp_context_create(void** ctx) {
@@ -497,6 +499,11 @@ extern "C" int pp_context_create(void** ctx) {
     hipEventCreateWithFlags(&c->fork[i], hipEventDisableTiming);
     hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
   }
+  for (int i = 0; i < 4; ++i) {
+    hipEventCreateWithFlags(&c->dfork[i], hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->djoin[i], hipEventDisableTiming);
+  }
+  c->pending = 0;
   *ctx = c;
   return PP_OK;
 }
@@ -506,8 +513,35 @@ extern "C" int pp_context_destroy(void* ctx) {
   PPContext* c = static_cast<PPContext*>(ctx);
   hipStreamSynchronize(c->aux);
   for (int i = 0; i < 16; ++i) { hipEventDestroy(c->fork[i]); hipEventDestroy(c->join[i]); }
+  for (int i = 0; i < 4; ++i) { hipEventDestroy(c->dfork[i]); hipEventDestroy(c->djoin[i]); }
   hipStreamDestroy(c->aux);
   delete c;
+  return PP_OK;
+}
+
+// Fused paths: the weight-gradient kernel of a chain depends only on what the data-gradient kernel left in `scratch` and
+// nothing downstream needs it before the optimiser, so with a context it is launched on the auxiliary stream and NOT
+// joined here: the caller's next kernels (small, latency-bound ones: colour-feature / geometry backward, ray and pose
+// backward) run beside it, and pp_context_join() is called before the scratch buffer or the gradients are touched again.
+static hipStream_t deferred_fork(void* ctx, hipStream_t main) {
+  PPContext* c = static_cast<PPContext*>(ctx);
+  if (!c || c->pending >= 4) return main;
+  hipEventRecord(c->dfork[c->pending], main);
+  hipStreamWaitEvent(c->aux, c->dfork[c->pending], 0);
+  return c->aux;
+}
+static void deferred_forked(void* ctx, hipStream_t used, hipStream_t main) {
+  PPContext* c = static_cast<PPContext*>(ctx);
+  if (!c || used == main) return;
+  hipEventRecord(c->djoin[c->pending], c->aux);
+  ++c->pending;
+}
+
+extern "C" int pp_context_join(void* ctx, void* stream) {
+  PPContext* c = static_cast<PPContext*>(ctx);
+  if (!c) return PP_OK;
+  for (int i = 0; i < c->pending; ++i) hipStreamWaitEvent(pp_stream(stream), c->djoin[i], 0);
+  c->pending = 0;
   return PP_OK;
 }
 
@@ -589,8 +623,13 @@ extern "C" int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld,
   PP_REQUIRE(capacity > 0 && in_ld % 32 == 0 && in_ld <= 128 && n_gemm >= 1 && n_gemm <= 8, "bad sizes");
   hipStream_t st = pp_stream(stream);
   if (in_ld == 64 && n_gemm == 3 && feat_grad && mlp_fused_enabled()) {
-    pp_launch_rgb_fused_bwd(params, feat, acts, out, out_grad, count, capacity, scratch, params_grad, feat_grad,
-                            logit_add_grad, logit_add_ld, st);
+    pp_launch_rgb_fused_bwd(params, acts, out, out_grad, count, capacity, scratch, params_grad, feat_grad, logit_add_grad,
+                            logit_add_ld, st);
+    const size_t FLS = (size_t)capacity * 128;
+    hipStream_t ws = deferred_fork(ctx, st);
+    pp_launch_wgrad_chain(scratch, acts + FLS, params_grad + RGF_W2, scratch + FLS, acts, params_grad + RGF_W1,
+                          scratch + 2 * FLS, feat, params_grad + RGF_W0, 64, count, 1, capacity, ws);
+    deferred_forked(ctx, ws, st);
     PP_CHECK_LAUNCH();
     return PP_OK;
   }
@@ -682,8 +721,10 @@ extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* a
   if (mlp_fused_enabled()) {
     // one fused data-gradient kernel (+ thin layers), then the three weight-gradient GEMMs on the Ybar it left behind
     pp_launch_warp_fused_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad, st);
+    hipStream_t ws = deferred_fork(ctx, st);
     pp_launch_wgrad_chain(scratch, acts + 2 * LS, params_grad + WP_W3, scratch + LS, acts + LS, params_grad + WP_W2,
-                          scratch + 2 * LS, acts, params_grad + WP_W1, 128, count, 4, rcap, st);
+                          scratch + 2 * LS, acts, params_grad + WP_W1, 128, count, 4, rcap, ws);
+    deferred_forked(ctx, ws, st);
     PP_CHECK_LAUNCH();
     return PP_OK;
   }

@@ -1078,15 +1078,13 @@ __global__ __launch_bounds__(256) void k_rgb_fused_bwd(const float* __restrict__
   }
 }
 
-int pp_launch_rgb_fused_bwd(const float* params, const float* feat, const float* acts, const float* rgb,
-                            const float* rgb_grad, const int32_t* count, int capacity, float* ybar, float* params_grad,
-                            float* feat_grad, float* logit_grad, int lg_ld, hipStream_t st) {
+int pp_launch_rgb_fused_bwd(const float* params, const float* acts, const float* rgb, const float* rgb_grad,
+                            const int32_t* count, int capacity, float* ybar, float* params_grad, float* feat_grad,
+                            float* logit_grad, int lg_ld, hipStream_t st) {
   const int ntiles = pp_div_up(capacity, TILE_ROWS);
   const int grid = ntiles < PP_FUSED_WGS ? ntiles : PP_FUSED_WGS;
   hipLaunchKernelGGL(k_rgb_fused_bwd, dim3(grid), dim3(256), 0, st, params, acts, rgb, rgb_grad, count, capacity, ybar,
                      params_grad, feat_grad, logit_grad, lg_ld);
-  const size_t LS = (size_t)capacity * 128;
-  return pp_launch_wgrad_chain(ybar, acts + LS, params_grad + RGF_W2, ybar + LS, acts, params_grad + RGF_W1, ybar + 2 * LS,
-                               feat, params_grad + RGF_W0, 64, count, 1, capacity, st);
+  return 0;
 }
 

@@ -114,7 +114,9 @@ class Workspace:
         self.g_gradient, self.g_pts, self.g_view_s = e(capacity, 3, **f), e(capacity, 3, **f), e(capacity, 3, **f)
         self.g_grad_deform, self.g_corr, self.g_sdf_deform = e(capacity, 9, **f), e(capacity, **f), e(capacity, **f)
         self.g_warp_out = e(capacity, 16, **f)
-        self.scratch = e(3 * capacity * 4 * 128 + 49152, **f)   # shared by both MLP backward chains (+ transposed weights)
+        self.scratch = e(3 * capacity * 4 * 128 + 49152, **f)   # Ybar of the warp chain (+ transposed weights, layered path)
+        self.scratch_rgb = e(3 * capacity * 128 + 49152, **f)   # Ybar of rgbnet: its weight-gradient kernel may still be
+        #                                                         reading it on the side stream while the warp chain runs
         self.g_rays_o, self.g_rays_d, self.g_viewdirs = e(N, 3, **f), e(N, 3, **f), e(N, 3, **f)
 
 
@@ -197,9 +199,12 @@ class RenderCore:
     def __init__(self, cfg: SceneConfig, use_side_stream=False):
         self.cfg = cfg
         import os
-        # Forking the weight-gradient GEMMs onto an auxiliary stream (pp_context) is implemented but OFF by default:
-        # measured on MI355X it is 4-5 % slower than the sequential chain (both GEMMs are matrix-pipe bound and the
-        # persistent data-gradient GEMM has to give up residency).  PP_SIDE_STREAM=1 turns it on for experiments.
+        # With a pp_context the weight-gradient kernel of each MLP chain runs on an auxiliary stream beside the small,
+        # latency-bound kernels that follow the chain's data-gradient kernel (colour-feature / geometry backward after
+        # rgbnet; ray / pose backward after the warp net) and is joined before the next register-hungry MLP kernel.
+        # Measured on MI355X (kernel trace): the overlap happens, but the small kernels only get the leftover wave slots
+        # (15 -> 45 us each) and the fork / join edges cost ~10 us per chain, so the step is 1 % SLOWER - OFF by default,
+        # PP_SIDE_STREAM=1 turns it on for experiments.
         self.use_side_stream = use_side_stream or os.environ.get('PP_SIDE_STREAM') == '1'
 
     # -- forward -------------------------------------------------------------------------------------------
@@ -223,7 +228,7 @@ class RenderCore:
     # -- backward ------------------------------------------------------------------------------------------
     def backward(self, ws, k0_cl, sdf, sdf_ab, rgbnet_p, warp_p, inv_s, pe_w, k0_grad_cl, sdf_ab_grad, rgbnet_grad,
                  warp_grad, g_depth=None, g_weights=None, g_gradient_ext=None, g_sdf_deform=None, g_grad_deform=None,
-                 g_correction=None, g_alpha_ext=None, g_rgb_ext=None, after_k0_grad=None):
+                 g_correction=None, g_alpha_ext=None, g_rgb_ext=None, after_k0_grad=None, defer_join=False):
         """Consumes ws.g_rgbm / ws.g_last / ws.g_cw (+ optional per-sample upstream grads), accumulates parameter
         grads (atomic +=) and leaves d/d ray_pts in ws.g_pts and the per-sample viewdir grads in ws.g_view_s."""
         cfg, sc = self.cfg, self.cfg.pp
@@ -234,7 +239,7 @@ class RenderCore:
         if g_rgb_ext is not None:
             ws.g_rgb.add_(g_rgb_ext)
         ctx = ops.side_context() if self.use_side_stream else None
-        ops.rgbnet_bwd(rgbnet_p, ws.feat, ws.rgb_acts, ws.rgb, ws.g_rgb, ws.count, ws.cap, ws.scratch,
+        ops.rgbnet_bwd(rgbnet_p, ws.feat, ws.rgb_acts, ws.rgb, ws.g_rgb, ws.count, ws.cap, ws.scratch_rgb,
                        rgbnet_grad, ws.g_feat, ctx)
         ops.color_feat_bwd(sc, k0_cl, ws.pts, ws.viewdirs, ws.ray_id, ws.gradient, pe_w, ws.count, ws.cap, ws.g_feat,
                            k0_grad_cl, ws.g_pts, ws.g_gradient, ws.g_view_s)
@@ -245,8 +250,12 @@ class RenderCore:
         ops.geometry_bwd(sc, sdf, sdf_ab, ws.pts, ws.warp_out, ws.viewdirs, ws.ray_id, ws.count, ws.cap, inv_s,
                          ws.g_alpha, ws.g_gradient, None, g_sdf_deform, g_grad_deform, g_correction, 1, ws.g_warp_out,
                          ws.g_pts, ws.g_view_s, sdf_ab_grad)
+        ops.context_join(ctx)           # rgbnet's weight-gradient kernel is done before the next register-hungry kernel
         ops.warp_bwd(warp_p, ws.pts, ws.warp_acts, ws.g_warp_out, ws.count, ws.cap, cfg.out_range, ws.scratch, warp_grad,
                      ws.g_pts, ctx)
+        if not defer_join:
+            ops.context_join(ctx)
+        return ctx
 
 
 class TrainEngine:
@@ -371,11 +380,14 @@ class TrainEngine:
                            k0_grad, P.view('sdf_ab', 'grad'), P.view('rgbnet', 'grad'), P.view('warp', 'grad'),
                            g_gradient_ext=add_sample_losses, g_sdf_deform=ws.g_sdf_deform,
                            g_grad_deform=ws.g_grad_deform, g_correction=ws.g_corr,
-                           after_k0_grad=None if self.dist is None else (lambda: self.dist.start_grid_reduce(self)))
+                           after_k0_grad=None if self.dist is None else (lambda: self.dist.start_grid_reduce(self)),
+                           defer_join=True)
+        ctx = ops.side_context() if self.core.use_side_stream else None
         ops.raygen_select_bwd(sc, ray_idx, self.c2w, self.intr, self.H, self.W, cfg.inverse_y, ws.rays_o, ws.rays_d,
                               ws.t_min, ws.ray_start, ws.g_pts, ws.step, ws.g_view_s, None, None, None, None, None, None,
                               None, self.c2w_grad)
         ops.pose_bwd(self.jac, self.c2w_grad, self.se3_grad)
+        ops.context_join(ctx)           # the warp net's weight gradients (side stream) before anything reads flat.grad
         return s_val, w_dyn
 
     def _upload_step_scalars(self, progress):

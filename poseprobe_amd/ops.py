@@ -181,6 +181,12 @@ def side_context():
     return _CTX[dev]
 
 
+def context_join(ctx):
+    """Current stream waits for every weight-gradient kernel deferred onto the context's auxiliary stream."""
+    if ctx is not None:
+        _lib.call('pp_context_join', ctx, _stream())
+
+
 def rgbnet_bwd(params, feat, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad, ctx=None):
     _lib.call('pp_rgbnet_bwd', _f(params), _f(feat), _f(acts), _f(rgb), _f(rgb_grad), _i(count), capacity,
               _f(scratch), _f(params_grad), _f(feat_grad), ctx, _stream())

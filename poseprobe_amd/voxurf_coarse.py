@@ -193,6 +193,7 @@ def _ws_alloc_backward(self):
     self.g_gradient, self.g_pts, self.g_view_s = e(cap, 3, **f), e(cap, 3, **f), e(cap, 3, **f)
     self.g_warp_out = e(cap, 16, **f)
     self.scratch = e(3 * cap * 4 * 128 + 49152, **f)
+    self.scratch_rgb = e(3 * cap * 128 + 49152, **f)
 
 
 Workspace.alloc_backward = _ws_alloc_backward
