@@ -30,11 +30,13 @@ HBM_PEAK_GBS = 8000.0       # MI355X spec (MI355X_MICROARCH.md: 8 TB/s spec, ~6.
 GRID_BYTES_PER_VOXEL = 384  # fused pass, C=12 fp32: read p,g,m,v (192) + write p',m,v,g=0 (192)
 
 
-def pmc_traffic(grid, voxels):
-    """HBM bytes per launch of k_grid_tv_adam from the committed rocprofv3 PMC passes (profiles/r01_grid_traffic.json:
-    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KB -> bytes), only when it was collected for this grid size."""
+def pmc_traffic(grid, voxels, sparse):
+    """HBM bytes per launch of k_grid_tv_adam from the committed rocprofv3 PMC passes (profiles/r01_grid_traffic*.json:
+    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KB -> bytes), only when it was collected for this grid size and for
+    this variant of the pass (dense / sparse-gradient)."""
     try:
-        rec = json.load(open(os.path.join(ROOT, 'profiles', 'r01_grid_traffic.json')))
+        name = 'r01_grid_traffic_sparse.json' if sparse else 'r01_grid_traffic.json'
+        rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
         if int(rec['grid']) == int(grid) and int(rec['voxels_per_launch']) == int(voxels):
             return float(rec['hbm_bytes_per_launch'])
     except Exception:
@@ -139,16 +141,17 @@ def main():
     # time the dominant kernel with HIP events on the launch stream (torch's current stream == our launch stream)
     from poseprobe_amd import ops
     ev = []
-    orig = ops.grid_tv_adam_step
+    def timed_grid_step(fn):
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*a, **k)
+            e1.record()
+            ev.append((e0, e1))
+        return wrapper
 
-    def timed_grid_step(*a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        orig(*a, **k)
-        e1.record()
-        ev.append((e0, e1))
-
-    ops.grid_tv_adam_step = timed_grid_step
+    ops.grid_tv_adam_step = timed_grid_step(ops.grid_tv_adam_step)                   # dense pass (ZeRO-1 slabs)
+    ops.grid_tv_adam_step_sparse = timed_grid_step(ops.grid_tv_adam_step_sparse)     # same kernel with the touched-voxel bitmap
     # second roofline: the two MLPs on the matrix cores (fp32 MFMA).  Every event pair drains the launch pipeline, so
     # these four extra pairs per step are taken in a short pass AFTER the timed region, not inside it.
     mlp_ev = []
@@ -191,7 +194,14 @@ def main():
     grid_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float('nan')
     xb, xe = eng.x_slab
     X, Y, Z = cfg.world_size
-    grid_bytes = GRID_BYTES_PER_VOXEL * (xe - xb) * Y * Z
+    # algorithmic bytes of the pass: p, m, v read + p', m, v written for every voxel (288 B at C=12), the gradient read
+    # + re-zeroed only for the voxels the scatter marked (96 B x marked fraction; fraction = 1 for the dense pass)
+    marked = 1.0
+    if (xb, xe) == (0, X) and not (dctx is not None and dctx.local_scatter):
+        bits = eng.k0_touched[1 - eng.touch_par].cpu().numpy().view(np.uint8)   # the bitmap the last step consumed
+        marked = float(np.unpackbits(bits).sum()) / (X * Y * Z)
+    per_voxel = GRID_BYTES_PER_VOXEL * (0.75 + 0.25 * marked)
+    grid_bytes = per_voxel * (xe - xb) * Y * Z
     achieved = grid_bytes / (grid_ms * 1e-3) / 1e9
     # MFMA-shaped work per sample: warp hidden GEMMs 3 layers x 4 rows x 2*128*128 x (fwd + 2 bwd),
     # rgbnet (64*128 + 2*128*128) x 2 x (fwd + 2 bwd)
@@ -208,9 +218,10 @@ def main():
                                    f'losses, backward, TV+Adam), {G}^3 grid, {cfg.n_samples} samples/ray, '
                                    f'N_rand={N}/GPU', 'grid': G, 'n_rand_per_gpu': N, 'samples_in_bbox_last_step': M,
                        'parallelism': (f'ray-sharded dp{world}, k0 gradient exchanged per sample (all-gather), replicated grid optimiser' if (dctx is None or dctx.mode == 'samples') else f'ray-sharded dp{world}, dense reduce-scatter + ZeRO-1 grid optimiser') if world > 1 else 'single GPU'},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_grid_tv_adam (fused TV-grad + Adam + zero-grad over k0)',
+            'roofline': {'bound': 'hbm', 'kernel': 'k_grid_tv_adam (fused TV-grad + Adam + zero-grad over k0, gradient touched only where the scatter marked)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': pmc_traffic(G, (xe - xb) * Y * Z), 'ms_per_launch': grid_ms, 'algorithmic_bytes_per_launch': grid_bytes},
+                         'traffic': pmc_traffic(G, (xe - xb) * Y * Z, marked < 1.0), 'ms_per_launch': grid_ms, 'algorithmic_bytes_per_launch': grid_bytes,
+                         'grad_voxels_marked': marked},
             'roofline_mfma': {'bound': 'mfma', 'kernel': 'warp + rgbnet MLP chains (layer-fused fwd / bwd-data / weight-gradient kernels, fp32 MFMA 32x32x2)',
                               'achieved': mlp_tflops, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': mlp_tflops / 157.3,
                               'ms_per_step': mlp_ms, 'flop_per_sample': flop_per_sample},

@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256) void k_grid_tv_adam(const float4* __restrict__
                                                       float4* __restrict__ v_, int X, int Y, int Z, int q4,
                                                       int x_begin, int x_end, int n_chunks, int chunk_len,
                                                       float tv_scale, float grad_scale, float b1, float b2, float eps,
-                                                      float step_size, float inv_sqrt_bc2, float* __restrict__ tv_out) {
+                                                      float step_size, float inv_sqrt_bc2, float* __restrict__ tv_out,
+                                                      const uint32_t* __restrict__ touched,
+                                                      uint32_t* __restrict__ touched_clear) {
   __shared__ float sm[4];
   const int plane = Y * Z * q4;                      // float4 per x-plane
   const int chunk = blockIdx.x % n_chunks;
@@ -64,10 +66,21 @@ __global__ __launch_bounds__(256) void k_grid_tv_adam(const float4* __restrict__
     size_t e = (size_t)xs * plane + i;
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f), pc = p_in[e], pn;
     if (xs > 0) pm = p_in[e - plane];
-    for (int x = xs; x < xe; ++x, e += plane) {
+    // Sparse gradient: the data-dependent part of the gradient is non-zero only in voxels the scatter marked (~7 % per
+    // step); for the others g == 0 is known without reading it and its zero-fill is a no-op.  The bitmap word of plane
+    // x+1 is fetched one iteration ahead; the OTHER parity's bitmap (consumed last step) is cleared on the way.
+    const int nyz = Y * Z;
+    size_t vx = (size_t)xs * nyz + vox;
+    uint32_t wcur = touched ? touched[vx >> 5] : 0xffffffffu, wnext = wcur;
+    for (int x = xs; x < xe; ++x, e += plane, vx += nyz) {
       const bool xh = x < X - 1;
       pn = xh ? p_in[e + plane] : pc;
-      float4 g = ldnt4(grad + e), m = ldnt4(m_ + e), v = ldnt4(v_ + e);
+      if (touched && x + 1 < xe) wnext = touched[(vx + nyz) >> 5];
+      const bool hit = (wcur >> (vx & 31)) & 1u;
+      if (touched_clear && (i % q4) == 0 && (vx & 31) == 0) touched_clear[vx >> 5] = 0u;
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (hit) g = ldnt4(grad + e);
+      float4 m = ldnt4(m_ + e), v = ldnt4(v_ + e);
       float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (x > 0) acc_sgn(tv, pc, pm);
       if (xh) { acc_sgn(tv, pc, pn); tv_local += abs4(pc, pn); }
@@ -85,9 +98,10 @@ __global__ __launch_bounds__(256) void k_grid_tv_adam(const float4* __restrict__
       stnt4(p_out + e, o);
       stnt4(m_ + e, m);
       stnt4(v_ + e, v);
-      stnt4(grad + e, make_float4(0.f, 0.f, 0.f, 0.f));
+      if (hit) stnt4(grad + e, make_float4(0.f, 0.f, 0.f, 0.f));
       pm = pc;
       pc = pn;
+      wcur = wnext;
     }
   }
   if (tv_out) {
@@ -143,10 +157,11 @@ __global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, float*
   if (zero_grad) grad[i] = 0.f;
 }
 
-extern "C" int pp_grid_tv_adam_step(const float* p_in, float* p_out, float* grad, float* exp_avg, float* exp_avg_sq,
+extern "C" int pp_grid_tv_adam_step_sparse(const float* p_in, float* p_out, float* grad, float* exp_avg, float* exp_avg_sq,
                                     int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, int32_t x_begin, int32_t x_end,
                                     float tv_scale, float grad_scale, float lr, float beta1, float beta2, float eps,
-                                    int32_t step, float* tv_out, void* stream) {
+                                    int32_t step, float* tv_out, const uint32_t* touched,
+                                            uint32_t* touched_clear, void* stream) {
   PP_REQUIRE(p_in && p_out && grad && exp_avg && exp_avg_sq, "null pointer");
   const int32_t size[3] = {size_x, size_y, size_z};
   PP_REQUIRE(p_in != p_out, "p_in and p_out must be distinct (ping-pong) buffers");
@@ -160,7 +175,8 @@ extern "C" int pp_grid_tv_adam_step(const float* p_in, float* p_out, float* grad
   const long long plane = (long long)size[1] * size[2] * q4;
   PP_REQUIRE(plane < (1ll << 31) && n < (1ll << 40), "grid too large for 32-bit plane indexing");
   // chunks: a multiple of 8 when possible so that chunk <-> XCD (blocks are dealt round-robin over the 8 XCDs)
-  int n_chunks = nx >= 64 ? 8 * (nx / 64 > 2 ? 2 : 1) : (nx >= 8 ? 8 : nx);
+  // measured (tools/bench_grid.py, MI355X): 16 chunks win from 128 planes up (160^3: 272 -> 256 us dense), 8 below
+  int n_chunks = nx >= 128 ? 16 : (nx >= 8 ? 8 : nx);
   if (const char* ev = getenv("PP_GRID_CHUNKS")) { int c = atoi(ev); if (c > 0 && c <= nx) n_chunks = c; }   // tuning hook
   const int chunk_len = (nx + n_chunks - 1) / n_chunks;
   n_chunks = (nx + chunk_len - 1) / chunk_len;
@@ -170,9 +186,17 @@ extern "C" int pp_grid_tv_adam_step(const float* p_in, float* p_out, float* grad
                      reinterpret_cast<float4*>(grad), reinterpret_cast<float4*>(exp_avg),
                      reinterpret_cast<float4*>(exp_avg_sq), size[0], size[1], size[2], q4, x_begin, x_end, n_chunks,
                      chunk_len, tv_scale, grad_scale, beta1, beta2, eps, (float)((double)lr / bc1),
-                     (float)(1.0 / sqrt(bc2)), tv_out);
+                     (float)(1.0 / sqrt(bc2)), tv_out, touched, touched_clear);
   PP_CHECK_LAUNCH();
   return PP_OK;
+}
+
+extern "C" int pp_grid_tv_adam_step(const float* p_in, float* p_out, float* grad, float* exp_avg, float* exp_avg_sq,
+                                    int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, int32_t x_begin,
+                                    int32_t x_end, float tv_scale, float grad_scale, float lr, float beta1, float beta2,
+                                    float eps, int32_t step, float* tv_out, void* stream) {
+  return pp_grid_tv_adam_step_sparse(p_in, p_out, grad, exp_avg, exp_avg_sq, size_x, size_y, size_z, channels, x_begin, x_end,
+                                     tv_scale, grad_scale, lr, beta1, beta2, eps, step, tv_out, nullptr, nullptr, stream);
 }
 
 extern "C" int pp_grid_tv_value(const float* p, int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels,

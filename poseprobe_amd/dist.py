@@ -141,7 +141,8 @@ class DistContext:
             from . import ops
             self._grid_work.wait()
             self._grid_work = None
-            ops.k0_scatter_packed(eng.cfg.pp, self._gathered, self.world, eng.ws.cap, eng.k0_grad)
+            ops.k0_scatter_packed(eng.cfg.pp, self._gathered, self.world, eng.ws.cap, eng.k0_grad,
+                                  eng.k0_touched[eng.touch_par])
             eng.x_slab = (0, X)
             self.all_reduce_small([eng.flat.grad, eng.se3_grad])
             eng.grad_scale = 1.0 / self.world

@@ -277,6 +277,11 @@ class TrainEngine:
         self.k0_cur = 0
         self.k0_grad, self.k0_m, self.k0_v = (torch.zeros(X, Y, Z, cfg.k0_dim, **f) for _ in range(3))
         self.sdf = torch.zeros(X, Y, Z, **f)
+        # one bit per voxel, two parities: the scatter of step n marks [n & 1], the fused optimiser pass reads it (voxels that
+        # were not reached keep a known-zero gradient: no read, no re-zeroing) and clears the other one for step n+1
+        self.k0_touched = torch.zeros(2, (X * Y * Z + 31) // 32, dtype=torch.int32, device=self.dev)
+        self.touch_par = 0
+        self._k0_marked = False
         self.flat = FlatParams(self.dev)
         self.se3 = torch.zeros(n_views, 6, **f)
         self.se3_grad, self.se3_m, self.se3_v = (torch.zeros(n_views, 6, **f) for _ in range(3))
@@ -346,6 +351,8 @@ class TrainEngine:
     # ---- one step -------------------------------------------------------------------------------------------
     def zero_grads(self):
         self.k0_grad.zero_()
+        self.k0_touched.zero_()
+        self._k0_marked = False
         self.flat.grad.zero_()
         self.se3_grad.zero_()
 
@@ -374,14 +381,24 @@ class TrainEngine:
             ops.loss_samples(w.gradient, w.grad_deform, w.warp_out, w.sdf_deform, w.count, w.cap, 1.0, w_dyn, ls,
                              w.g_gradient, w.g_grad_deform, w.g_corr, w.g_sdf_deform, w.loss_out)
 
-        # multi-GPU "samples" mode: no local k0 scatter, the gathered scatter inputs of all ranks are replayed later
-        k0_grad = self.k0_grad if (self.dist is None or self.dist.local_scatter) else None
+        # The k0 scatter is issued from here (not inside colour-feature backward) so that it can mark the voxels it reaches:
+        # single GPU = right after the colour-feature backward; multi-GPU "samples" mode = replayed for all ranks' gathered
+        # samples at the end of the backward; "zero1" = dense reduce-scatter, no marking (every voxel may be non-zero).
+        dense_exchange = self.dist is not None and self.dist.local_scatter
+        k0_grad = self.k0_grad if dense_exchange else None
+        self._k0_marked = not dense_exchange
+        touched = self.k0_touched[self.touch_par]
+
+        def after_k0():
+            if self.dist is None:
+                ops.k0_scatter_samples(sc, ws.pts, ws.count, ws.cap, ws.g_feat, self.k0_grad, touched)
+            else:
+                self.dist.start_grid_reduce(self)
         self.core.backward(ws, self.k0_cl, self.sdf, P.view('sdf_ab'), P.view('rgbnet'), P.view('warp'), inv_s, self.pe_w,
                            k0_grad, P.view('sdf_ab', 'grad'), P.view('rgbnet', 'grad'), P.view('warp', 'grad'),
                            g_gradient_ext=add_sample_losses, g_sdf_deform=ws.g_sdf_deform,
                            g_grad_deform=ws.g_grad_deform, g_correction=ws.g_corr,
-                           after_k0_grad=None if self.dist is None else (lambda: self.dist.start_grid_reduce(self)),
-                           defer_join=True)
+                           after_k0_grad=after_k0, defer_join=True)
         ctx = ops.side_context() if self.core.use_side_stream else None
         ops.raygen_select_bwd(sc, ray_idx, self.c2w, self.intr, self.H, self.W, cfg.inverse_y, ws.rays_o, ws.rays_d,
                               ws.t_min, ws.ray_start, ws.g_pts, ws.step, ws.g_view_s, None, None, None, None, None, None,
@@ -410,8 +427,16 @@ class TrainEngine:
         tv_scale = self.loss_scale * self.w_tv / (3.0 * X * Y * Z * cfg.k0_dim)
         src, dst = self.k0[self.k0_cur], self.k0[1 - self.k0_cur]
         xb, xe = self.x_slab
-        ops.grid_tv_adam_step(src, dst, self.k0_grad, self.k0_m, self.k0_v, cfg.world_size, cfg.k0_dim, xb, xe, tv_scale,
-                              grad_scale, self.lr['k0'], 0.9, 0.99, 1e-8, self.n_step, self.ws.tv_out)
+        if self._k0_marked and (xb, xe) == (0, X):
+            cur = self.touch_par
+            ops.grid_tv_adam_step_sparse(src, dst, self.k0_grad, self.k0_m, self.k0_v, cfg.world_size, cfg.k0_dim, xb, xe,
+                                         tv_scale, grad_scale, self.lr['k0'], 0.9, 0.99, 1e-8, self.n_step, self.ws.tv_out,
+                                         self.k0_touched[cur], self.k0_touched[1 - cur])
+            self.touch_par = 1 - cur
+            self._k0_marked = False
+        else:
+            ops.grid_tv_adam_step(src, dst, self.k0_grad, self.k0_m, self.k0_v, cfg.world_size, cfg.k0_dim, xb, xe, tv_scale,
+                                  grad_scale, self.lr['k0'], 0.9, 0.99, 1e-8, self.n_step, self.ws.tv_out)
         self.k0_cur = 1 - self.k0_cur
         ops.adam_flat(self.flat.data, self.flat.grad, self.flat.m, self.flat.v, self.seg_end, self.seg_lr, grad_scale, 0.9,
                       0.99, 1e-8, self.n_step, 1)

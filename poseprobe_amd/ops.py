@@ -159,8 +159,14 @@ def k0_pack_samples(pts, feat_grad, count, capacity, k0_dim, packed):
     _lib.call('pp_k0_pack_samples', _f(pts), _f(feat_grad), _i(count), capacity, int(k0_dim), _f(packed), _stream())
 
 
-def k0_scatter_packed(sc, packed, n_shards, capacity, k0_grad_cl):
-    _lib.call('pp_k0_scatter_packed', ctypes.byref(sc), _f(packed), int(n_shards), capacity, _f(k0_grad_cl), _stream())
+def k0_scatter_packed(sc, packed, n_shards, capacity, k0_grad_cl, touched=None):
+    _lib.call('pp_k0_scatter_packed', ctypes.byref(sc), _f(packed), int(n_shards), capacity, _f(k0_grad_cl), _i(touched),
+              _stream())
+
+
+def k0_scatter_samples(sc, pts, count, capacity, feat_grad, k0_grad_cl, touched=None):
+    _lib.call('pp_k0_scatter_samples', ctypes.byref(sc), _f(pts), _i(count), capacity, _f(feat_grad), _f(k0_grad_cl),
+              _i(touched), _stream())
 
 
 # ------------------------------------------------------------------------------------------- MLPs
@@ -221,6 +227,14 @@ def grid_tv_adam_step(p_in, p_out, grad, exp_avg, exp_avg_sq, size, channels, x_
     _lib.call('pp_grid_tv_adam_step', _f(p_in), _f(p_out), _f(grad), _f(exp_avg), _f(exp_avg_sq),
               int(size[0]), int(size[1]), int(size[2]), channels, x_begin, x_end, float(tv_scale), float(grad_scale),
               float(lr), float(beta1), float(beta2), float(eps), int(step), _f(tv_out), _stream())
+
+
+def grid_tv_adam_step_sparse(p_in, p_out, grad, exp_avg, exp_avg_sq, size, channels, x_begin, x_end, tv_scale, grad_scale,
+                             lr, beta1, beta2, eps, step, tv_out, touched, touched_clear):
+    _lib.call('pp_grid_tv_adam_step_sparse', _f(p_in), _f(p_out), _f(grad), _f(exp_avg), _f(exp_avg_sq),
+              int(size[0]), int(size[1]), int(size[2]), channels, x_begin, x_end, float(tv_scale), float(grad_scale),
+              float(lr), float(beta1), float(beta2), float(eps), int(step), _f(tv_out), _i(touched), _i(touched_clear),
+              _stream())
 
 
 def grid_tv_value(p, size, channels, out):

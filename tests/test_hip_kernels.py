@@ -193,3 +193,45 @@ def test_grid_tv_adam_step_matches_oracle(shape):
     tv2 = torch.zeros(1, device='cuda')
     ops.grid_tv_value(p_in, (X, Y, Z), C, tv2)
     assert_close(tv2.cpu()[0] / (3 * k0.numel()), tv.detach(), rtol=1e-5, name='tv value (standalone)')
+
+
+@pytest.mark.parametrize('shape', [(5, 6, 7), (16, 12, 9), (40, 32, 32)])
+def test_sparse_grid_step_is_bit_identical_to_dense(shape):
+    """pp_grid_tv_adam_step_sparse with the scatter's touched-voxel bitmap == the dense pass, bit for bit: parameters,
+    both moments and the zero-filled gradient (the TV value up to summation order); the previous step's bitmap is cleared."""
+    from poseprobe_amd import ops
+    X, Y, Z = shape
+    C = 12
+    g = torch.Generator().manual_seed(5)
+    p = (torch.randn(X, Y, Z, C, generator=g) * 0.1).cuda()
+    m0 = (torch.randn(X, Y, Z, C, generator=g) * 1e-3).cuda()
+    v0 = (torch.rand(X, Y, Z, C, generator=g) * 1e-5).cuda()
+    hit = torch.rand(X, Y, Z, generator=g) < 0.07                      # ~7 % of the voxels receive data gradient
+    grad = torch.zeros(X, Y, Z, C)
+    grad[hit] = torch.randn(int(hit.sum()), C, generator=g) * 1e-2
+    grad[hit.nonzero()[0][0], hit.nonzero()[0][1], hit.nonzero()[0][2]] = 0.0   # a marked voxel whose gradient is exactly 0
+    nvox = X * Y * Z
+    words = (nvox + 31) // 32
+    bits = torch.zeros(words * 32, dtype=torch.int64)
+    bits[:nvox] = hit.reshape(-1).long()
+    w = (bits.view(words, 32) << torch.arange(32)).sum(1)
+    touched = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).cuda()
+    stale = torch.full((words,), -1, dtype=torch.int32, device='cuda')   # last step's bitmap: must come back all zero
+    outs = []
+    for sparse in (False, True):
+        gr, m, v = grad.cuda().clone(), m0.clone(), v0.clone()
+        po = torch.empty_like(p)
+        tv = torch.zeros(1, device='cuda')
+        a = (p, po, gr, m, v, (X, Y, Z), C, 0, X, 1e-4, 0.5, 0.1, 0.9, 0.99, 1e-8, 3, tv)
+        if sparse:
+            ops.grid_tv_adam_step_sparse(*a, touched, stale)
+        else:
+            ops.grid_tv_adam_step(*a)
+        torch.cuda.synchronize()
+        outs.append((po.cpu(), m.cpu(), v.cpu(), gr.cpu(), tv.cpu()))
+    for a, b, name in zip(outs[0][:4], outs[1][:4], ('p', 'exp_avg', 'exp_avg_sq', 'grad')):
+        assert torch.equal(a, b), name
+    # the TV value is a sum of per-block partials combined with float atomics: same terms, unordered
+    assert abs(float(outs[0][4]) - float(outs[1][4])) <= 1e-5 * abs(float(outs[0][4]))
+    assert float(outs[1][3].abs().max()) == 0
+    assert int(stale.abs().sum()) == 0

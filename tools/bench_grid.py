@@ -1,0 +1,36 @@
+"""Isolated A/B of the fused TV+Adam grid pass: dense vs sparse-gradient (touched bitmap).  python tools/bench_grid.py [G] [frac]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from poseprobe_amd import ops
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 160
+frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.084
+dev = 'cuda'
+C = 12
+p = torch.randn(G, G, G, C, device=dev) * 0.1
+po = torch.empty_like(p)
+m, v, g = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+nvox = G ** 3
+words = (nvox + 31) // 32
+# clustered marks (rays are lines): mark runs of 4 consecutive voxels
+hit = (torch.rand(nvox // 4, device=dev) < frac).repeat_interleave(4)
+bits = hit.view(words, 32).long()
+w = (bits << torch.arange(32, device=dev)).sum(1)
+touched = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+other = torch.zeros(words, dtype=torch.int32, device=dev)
+tv = torch.zeros(1, device=dev)
+print(f'G={G} marked {float(hit.float().mean()):.3f}')
+def run(sparse, n=20):
+    a = (p, po, g, m, v, (G, G, G), C, 0, G, 1e-4, 1.0, 0.1, 0.9, 0.99, 1e-8, 3, tv)
+    f = (lambda: ops.grid_tv_adam_step_sparse(*a, touched, other)) if sparse else (lambda: ops.grid_tv_adam_step(*a))
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+for rep in range(2):
+    td, ts = run(False), run(True)
+    bd, bs = 384 * nvox, (288 + 96 * float(hit.float().mean())) * nvox
+    print(f'dense {td:7.1f} us = {bd / td / 1e6:6.2f} TB/s   sparse {ts:7.1f} us = {bs / ts / 1e6:6.2f} TB/s (algorithmic)')
