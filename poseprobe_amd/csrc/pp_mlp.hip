@@ -9,12 +9,14 @@
 // run in reverse with identical masking.  This replaces the reference's four autograd.grad(create_graph=True)
 // passes and their double backward (lib/voxurf_coarse.py:968-984) by plain matrix products.
 //
-// GEMM tiling: work-group = 256 threads = 4 wavefronts (2x2), block tile 128 rows x 128 features, BK = 32,
-// each wavefront owns a 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 VGPRs).  LDS operand tiles are stored
-// [row][k] with an odd row stride (33) so the per-lane A/B fragment reads (lane -> row, half-wave -> k) are
-// bank-conflict free for ds_read_b32.  In the accumulator layout a lane holds ONE feature column and rows
-// (reg&3) + 8*(reg>>2) + 4*(lane>>5): the four rows of a sample are registers 4q..4q+3 of the same lane, so the
-// 4-row masking needs no cross-lane traffic.
+// This file holds the C-ABI entry points of both MLPs and the LAYER-BY-LAYER kernels: a persistent NT GEMM (work-group =
+// 4 wavefronts in 2x2, 64-row x 128-feature tile, K-chunks of 32 through LDS rows of 36 floats so that a lane fetches its
+// four operands of consecutive MFMAs with one ds_read_b128; next chunk / next tile prefetched into registers behind the
+// MFMA block), a split-K TN GEMM for the weight gradients and the thin first / last layers.  They serve generic MLP shapes
+// (DirectVoxGO twin) and A/B runs (PP_MLP_FUSED=0); the Voxurf shapes run through the layer-fused kernels of
+// pp_mlp_fused.hip.  In the accumulator layout a lane holds ONE feature column and rows (reg&3) + 8*(reg>>2) +
+// 4*(lane>>5): the four rows of a sample are registers 4q..4q+3 of the same lane, so the 4-row masking needs no
+// cross-lane traffic.
 #include "pp_common.h"
 #include "pp_mlp_fused.h"
 #include <stdlib.h>
