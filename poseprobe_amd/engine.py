@@ -423,6 +423,17 @@ class TrainEngine:
         self.n_step += 1
         for k in self.lr:                       # per-step exponential decay precedes the step (recon_scene.py:742-768)
             self.lr[k] *= self.decay
+        self._k0_step(self.lr['k0'], self.n_step, grad_scale)
+        ops.adam_flat(self.flat.data, self.flat.grad, self.flat.m, self.flat.v, self.seg_end, self.seg_lr, grad_scale, 0.9,
+                      0.99, 1e-8, self.n_step, 1)
+        if optimize_pose:
+            ops.adam_flat(self.se3.view(-1), self.se3_grad.view(-1), self.se3_m.view(-1), self.se3_v.view(-1),
+                          self.pose_seg_end, self.pose_seg_lr, grad_scale, 0.9, 0.999, 1e-8, self.n_step, 1)
+            self.lr_pose *= self.pose_gamma
+
+    def _k0_step(self, lr_k0, n_step, grad_scale):
+        """Fused TV + Adam pass over the colour grid (ping-pong buffers flip)."""
+        cfg = self.cfg
         X, Y, Z = cfg.world_size
         tv_scale = self.loss_scale * self.w_tv / (3.0 * X * Y * Z * cfg.k0_dim)
         src, dst = self.k0[self.k0_cur], self.k0[1 - self.k0_cur]
@@ -430,20 +441,14 @@ class TrainEngine:
         if self._k0_marked and (xb, xe) == (0, X):
             cur = self.touch_par
             ops.grid_tv_adam_step_sparse(src, dst, self.k0_grad, self.k0_m, self.k0_v, cfg.world_size, cfg.k0_dim, xb, xe,
-                                         tv_scale, grad_scale, self.lr['k0'], 0.9, 0.99, 1e-8, self.n_step, self.ws.tv_out,
+                                         tv_scale, grad_scale, lr_k0, 0.9, 0.99, 1e-8, n_step, self.ws.tv_out,
                                          self.k0_touched[cur], self.k0_touched[1 - cur])
             self.touch_par = 1 - cur
             self._k0_marked = False
         else:
             ops.grid_tv_adam_step(src, dst, self.k0_grad, self.k0_m, self.k0_v, cfg.world_size, cfg.k0_dim, xb, xe, tv_scale,
-                                  grad_scale, self.lr['k0'], 0.9, 0.99, 1e-8, self.n_step, self.ws.tv_out)
+                                  grad_scale, lr_k0, 0.9, 0.99, 1e-8, n_step, self.ws.tv_out)
         self.k0_cur = 1 - self.k0_cur
-        ops.adam_flat(self.flat.data, self.flat.grad, self.flat.m, self.flat.v, self.seg_end, self.seg_lr, grad_scale, 0.9,
-                      0.99, 1e-8, self.n_step, 1)
-        if optimize_pose:
-            ops.adam_flat(self.se3.view(-1), self.se3_grad.view(-1), self.se3_m.view(-1), self.se3_v.view(-1),
-                          self.pose_seg_end, self.pose_seg_lr, grad_scale, 0.9, 0.999, 1e-8, self.n_step, 1)
-            self.lr_pose *= self.pose_gamma
 
     def train_step(self, ray_idx, jitter, global_step, optimize_pose=True):
         """Gradients are zeroed by the optimiser kernels themselves after use; call zero_grads() once before the
