@@ -30,6 +30,19 @@ def run(sparse, n=20):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+def run_cold(sparse, n=10):
+    """Each launch preceded by a 2 GB streaming write + a burst of MFMA-free ALU work: caches / TLBs see other data first."""
+    big = torch.empty(512 * 1024 * 1024, device=dev)
+    a = (p, po, g, m, v, (G, G, G), C, 0, G, 1e-4, 1.0, 0.1, 0.9, 0.99, 1e-8, 3, tv)
+    f = (lambda: ops.grid_tv_adam_step_sparse(*a, touched, other)) if sparse else (lambda: ops.grid_tv_adam_step(*a))
+    ts = []
+    for _ in range(n):
+        big.fill_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); f(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return sum(ts[2:]) / len(ts[2:])
+print(f'cold (2 GB written before every launch): dense {run_cold(False):7.1f} us   sparse {run_cold(True):7.1f} us')
 for rep in range(2):
     td, ts = run(False), run(True)
     bd, bs = 384 * nvox, (288 + 96 * float(hit.float().mean())) * nvox
