@@ -462,6 +462,63 @@ class TrainEngine:
             self.dist.gather_parameters(self)
         return out
 
+    # ---- checkpoint / resume (wire format of recon_scene.save_checkpoints, lib/recon_scene.py:779-790) -------------
+    RGBNET_KEYS = ('rgbnet.0', 'rgbnet.2.0', 'rgbnet.3.0', 'rgbnet.4')
+
+    def model_state_dict(self):
+        """The trainable state under the reference's state_dict names and logical shapes (lib/voxurf_coarse.py module tree,
+        SURVEY 8b), so that `Voxurf.load_state_dict(..., strict=False)` of either implementation accepts it."""
+        c = lambda t: t.detach().clone().cpu()
+        cfg, P = self.cfg, self.flat
+        sd = {'sdf_alpha': c(P.view('sdf_ab')[0:1]), 'sdf_beta': c(P.view('sdf_ab')[1:2]),
+              'xyz_min': torch.tensor(np.asarray(cfg.xyz_min, dtype=np.float32)),
+              'xyz_max': torch.tensor(np.asarray(cfg.xyz_max, dtype=np.float32)),
+              'sdf.grid': c(self.sdf)[None, None], 'k0.grid': c(self.k0_reference_layout()).contiguous()}
+        for name in ('sdf', 'k0'):
+            sd[name + '.xyz_min'], sd[name + '.xyz_max'] = sd['xyz_min'].clone(), sd['xyz_max'].clone()
+        for key, (W, b) in zip(self.RGBNET_KEYS, unpack_rgbnet(P.view('rgbnet'))):
+            sd[key + '.weight'], sd[key + '.bias'] = c(W).contiguous(), c(b)
+        for i, (W, b) in enumerate(unpack_warp(P.view('warp'))):
+            sd[f'warp_network.deform_net.net.net.{i}.0.weight'] = c(W)
+            sd[f'warp_network.deform_net.net.net.{i}.0.bias'] = c(b)
+        return sd
+
+    def load_model_state_dict(self, sd):
+        rg = [(sd[k + '.weight'], sd[k + '.bias']) for k in self.RGBNET_KEYS]
+        wp = [(sd[f'warp_network.deform_net.net.net.{i}.0.weight'], sd[f'warp_network.deform_net.net.net.{i}.0.bias'])
+              for i in range(5)]
+        self.load_reference_params(sd['k0.grid'], sd['sdf.grid'], sd['sdf_alpha'], sd['sdf_beta'], rg, wp)
+
+    def save_checkpoint(self, path, global_step):
+        """Keys as the reference writes them (`global_step`, `current_pose`, `model_state_dict`, `optimizer_state_dict`);
+        the optimiser entry holds this engine's flat Adam state (the reference stores a torch optimizer state_dict there)."""
+        ops.pose_fwd(self.se3, self.w2c_init, self.refine_mask, self.w2c, self.c2w, self.jac)
+        c = lambda t: t.detach().clone().cpu()
+        opt = {'format': 'poseprobe_amd.TrainEngine/1', 'n_step': self.n_step, 'lr': dict(self.lr), 'lr_pose': self.lr_pose,
+               'k0.exp_avg': c(self.k0_m), 'k0.exp_avg_sq': c(self.k0_v), 'flat.exp_avg': c(self.flat.m),
+               'flat.exp_avg_sq': c(self.flat.v), 'se3.exp_avg': c(self.se3_m), 'se3.exp_avg_sq': c(self.se3_v)}
+        torch.save({'global_step': int(global_step), 'current_pose': [c(p) for p in self.w2c],
+                    'se3_refine': c(self.se3), 'w2c_init': c(self.w2c_init),
+                    'model_state_dict': self.model_state_dict(), 'optimizer_state_dict': opt}, path)
+
+    def load_checkpoint(self, path, reload_optimizer=True):
+        """-> global_step.  Accepts checkpoints written by save_checkpoint and, for the model part, any checkpoint whose
+        `model_state_dict` uses the reference's names (weights_only load: nothing in the file is executed)."""
+        ck = torch.load(path, map_location='cpu', weights_only=True)
+        self.load_model_state_dict(ck['model_state_dict'])
+        d = lambda t: t.to(self.dev)
+        if 'se3_refine' in ck:
+            self.se3.copy_(d(ck['se3_refine']))
+            self.w2c_init.copy_(d(ck['w2c_init']))
+        opt = ck.get('optimizer_state_dict', {})
+        if reload_optimizer and opt.get('format') == 'poseprobe_amd.TrainEngine/1':
+            self.n_step, self.lr, self.lr_pose = int(opt['n_step']), dict(opt['lr']), float(opt['lr_pose'])
+            self.k0_m.copy_(d(opt['k0.exp_avg'])); self.k0_v.copy_(d(opt['k0.exp_avg_sq']))
+            self.flat.m.copy_(d(opt['flat.exp_avg'])); self.flat.v.copy_(d(opt['flat.exp_avg_sq']))
+            self.se3_m.copy_(d(opt['se3.exp_avg'])); self.se3_v.copy_(d(opt['se3.exp_avg_sq']))
+        self.zero_grads()
+        return int(ck.get('global_step', 0))
+
     def losses(self):
         """dict of the unweighted loss scalars of the last step (one D2H copy)."""
         v = self.ws.loss_out.cpu().numpy()

@@ -142,3 +142,44 @@ def test_dist_modes_on_one_rank_match_plain_engine(mode):
     assert (np.abs(a - b) > 1e-4).mean() < 0.02
     assert_close(c(sharded.se3), c(plain.se3), rtol=0, atol=2e-4, name=f'se3 ({mode})')
     assert (np.abs(c(sharded.flat.data) - c(plain.flat.data)) > 1e-4).mean() < 0.02
+
+
+def test_checkpoint_resume_reproduces_the_trajectory(tmp_path):
+    """save_checkpoint / load_checkpoint (reference key layout, weights_only load): training 2+2 steps through a
+    checkpoint equals training 4 steps straight (same budget as the other trajectory tests: scatter atomics are unordered),
+    and the model part loads into the drop-in Voxurf module under the reference's state_dict names."""
+    from poseprobe_amd import synthetic as syn
+    d = load('forward_g8_s10.npz')
+    V, H, W = d['images'].shape[:3]
+
+    def run(eng, steps):
+        for s in steps:
+            idx, jit = syn.step_randomness(V * H * W, int(d['n_rand']), seed=70 + s)
+            eng.train_step(torch.tensor(idx, dtype=torch.int32, device='cuda'), torch.tensor(jit, device='cuda'), 10 + s)
+
+    a, _ = build_engine(d, pose_iters=1000)
+    a.zero_grads()
+    run(a, range(4))
+    b, _ = build_engine(d, pose_iters=1000)
+    b.zero_grads()
+    run(b, range(2))
+    path = str(tmp_path / 'last_ckpt.tar')
+    b.save_checkpoint(path, global_step=12)
+    c2, _ = build_engine(d, pose_iters=1000)
+    with torch.no_grad():                      # wipe what build_engine loaded: everything must come from the file
+        c2.k0_cl.zero_(); c2.flat.data.zero_(); c2.se3.zero_()
+    assert c2.load_checkpoint(path) == 12
+    run(c2, range(2, 4))
+    torch.cuda.synchronize()
+    n = lambda t: t.detach().cpu().numpy()
+    assert (np.abs(n(c2.k0_cl) - n(a.k0_cl)) > 1e-4).mean() < 0.02
+    assert_close(n(c2.se3), n(a.se3), rtol=0, atol=2e-4, name='se3 after resume')
+    assert (np.abs(n(c2.flat.data) - n(a.flat.data)) > 1e-4).mean() < 0.02
+    assert c2.n_step == a.n_step and abs(c2.lr['k0'] - a.lr['k0']) < 1e-12
+    ck = torch.load(path, weights_only=True)
+    assert {'global_step', 'current_pose', 'model_state_dict', 'optimizer_state_dict'} <= set(ck.keys())
+    from tests.test_hip_dropin import make_model
+    m = make_model(d)
+    missing, unexpected = m.load_state_dict(ck['model_state_dict'], strict=False)
+    assert not unexpected, unexpected
+    assert torch.equal(m.k0.grid.detach().cpu(), ck['model_state_dict']['k0.grid'])
