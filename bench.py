@@ -151,7 +151,7 @@ def main():
         return wrapper
 
     ops.grid_tv_adam_step = timed_grid_step(ops.grid_tv_adam_step)                   # dense pass (ZeRO-1 slabs)
-    ops.grid_tv_adam_step_sparse = timed_grid_step(ops.grid_tv_adam_step_sparse)     # same kernel with the touched-voxel bitmap
+    ops.grid_tv_adam_step_sparse = timed_grid_step(ops.grid_tv_adam_step_sparse)     # same kernel with the touched-voxel map
     # second roofline: the two MLPs on the matrix cores (fp32 MFMA).  Every event pair drains the launch pipeline, so
     # these four extra pairs per step are taken in a short pass AFTER the timed region, not inside it.
     mlp_ev = []
@@ -198,8 +198,7 @@ def main():
     # + re-zeroed only for the voxels the scatter marked (96 B x marked fraction; fraction = 1 for the dense pass)
     marked = 1.0
     if (xb, xe) == (0, X) and not (dctx is not None and dctx.local_scatter):
-        bits = eng.k0_touched[1 - eng.touch_par].cpu().numpy().view(np.uint8)   # the bitmap the last step consumed
-        marked = float(np.unpackbits(bits).sum()) / (X * Y * Z)
+        marked = float(eng.k0_touched[1 - eng.touch_par].ne(0).sum().item()) / (X * Y * Z)   # the map the last step consumed
     per_voxel = GRID_BYTES_PER_VOXEL * (0.75 + 0.25 * marked)
     grid_bytes = per_voxel * (xe - xb) * Y * Z
     achieved = grid_bytes / (grid_ms * 1e-3) / 1e9

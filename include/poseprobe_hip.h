@@ -157,11 +157,11 @@ int pp_geometry_bwd(const pp_scene* sc, const float* sdf_grid, const float* sdf_
 int pp_k0_pack_samples(const float* pts, const float* feat_grad, const int32_t* count, int32_t capacity, int32_t k0_dim,
                        float* packed, void* stream);
 int pp_k0_scatter_packed(const pp_scene* sc, const float* packed, int32_t n_shards, int32_t capacity, float* k0_grad_cl,
-                         uint32_t* touched /*optional: see pp_grid_tv_adam_step_sparse*/, void* stream);
-/* The scatter half of pp_color_feat_bwd on its own (same kernel), optionally marking the voxels it reaches in a bitmap of
- * one bit per voxel (word = voxel >> 5, voxel = (x*Y + y)*Z + z). */
+                         uint8_t* touched /*optional: see pp_grid_tv_adam_step_sparse*/, void* stream);
+/* The scatter half of pp_color_feat_bwd on its own (same kernel), optionally marking the voxels it reaches in a map of
+ * one byte per voxel (index = (x*Y + y)*Z + z; plain stores of 1, no atomics). */
 int pp_k0_scatter_samples(const pp_scene* sc, const float* pts, const int32_t* count, int32_t capacity,
-                          const float* feat_grad, float* k0_grad_cl, uint32_t* touched /*optional*/, void* stream);
+                          const float* feat_grad, float* k0_grad_cl, uint8_t* touched /*optional*/, void* stream);
 
 /* ---------------------------------------------------------------- colour features: DenseGrid.forward for k0
  * (lib/grid.py:47-58, zeros padding), BARF positional encoding of xyz and view (voxurf_coarse.py:721-732,
@@ -239,14 +239,14 @@ int pp_grid_tv_adam_step(const float* p_in, float* p_out, float* grad, float* ex
                          int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, int32_t x_begin,
                          int32_t x_end, float tv_scale, float grad_scale, float lr, float beta1, float beta2,
                          float eps, int32_t step, float* tv_out, void* stream);
-/* Same pass for a SPARSE data gradient: `touched` (one bit per voxel, written by pp_k0_scatter_samples / _packed) tells
+/* Same pass for a SPARSE data gradient: `touched` (one byte per voxel, written by pp_k0_scatter_samples / _packed) tells
  * which voxels can hold a non-zero grad; for all others grad is neither read nor re-zeroed (96 of the 384 B/voxel).
  * Results are bit-identical to the dense pass as long as every non-zero grad voxel is marked.  `touched_clear` (the
- * bitmap consumed by the PREVIOUS step, or NULL) is zeroed on the way; touched == NULL = dense behaviour. */
+ * map consumed by the PREVIOUS step, or NULL) is zeroed on the way; touched == NULL = dense behaviour. */
 int pp_grid_tv_adam_step_sparse(const float* p_in, float* p_out, float* grad, float* exp_avg, float* exp_avg_sq,
                                 int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, int32_t x_begin,
                                 int32_t x_end, float tv_scale, float grad_scale, float lr, float beta1, float beta2,
-                                float eps, int32_t step, float* tv_out, const uint32_t* touched, uint32_t* touched_clear,
+                                float eps, int32_t step, float* tv_out, const uint8_t* touched, uint8_t* touched_clear,
                                 void* stream);
 /* Flat Adam over a packed parameter buffer with per-segment learning rates: seg_end[n_seg], seg_lr[n_seg]. */
 int pp_adam_flat(float* p, float* grad, float* exp_avg, float* exp_avg_sq, int32_t n, const int32_t* seg_end,

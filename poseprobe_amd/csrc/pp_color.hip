@@ -200,24 +200,22 @@ __global__ __launch_bounds__(256) void k_color_feat_bwd(SceneDev sc, const float
 // backward, part 2: k0 gradient scatter.  16 lanes per sample, lane = channel: every atomic wave-instruction
 // carries 4 contiguous C*4-byte segments instead of 64 scattered dwords (MI355X float atomics execute at the memory
 // side in 64-B requests; one lane per row is ~17x slower - guide 'Global float atomics').
-// `touched` (optional): one bit per voxel, set for every voxel that receives a contribution (lane 0 of a sample marks all
-// in-range corners, whatever the gradient values - over-marking is harmless).  The fused optimiser pass then neither
-// reads nor re-zeroes the gradient of unmarked voxels (pp_grid_tv_adam_step_sparse).
-__device__ __forceinline__ void k0_mark(const SceneDev& sc, const K0Tri& tr, uint32_t* __restrict__ touched) {
+// `touched` (optional): one byte per voxel, set to 1 for every voxel that receives a contribution (lane 0 of a sample marks all
+// in-range corners, whatever the gradient values - over-marking is harmless).  Plain byte stores: every writer stores the
+// same value, so no atomics are needed (a bitmap with atomicOr costs +20 us of same-word serialisation here).  The
+// fused optimiser pass then neither reads nor re-zeroes the gradient of unmarked voxels (pp_grid_tv_adam_step_sparse).
+__device__ __forceinline__ void k0_mark(const SceneDev& sc, const K0Tri& tr, uint8_t* __restrict__ touched) {
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     size_t off; float w;
-    if (k0_corner(sc, tr, c, off, w)) {
-      const size_t v = off / (size_t)sc.C;
-      atomicOr(&touched[v >> 5], 1u << (v & 31));
-    }
+    if (k0_corner(sc, tr, c, off, w)) touched[off / (size_t)sc.C] = 1;
   }
 }
 
 __global__ __launch_bounds__(256) void k_k0_scatter(SceneDev sc, const float* __restrict__ pts,
                                                     const int32_t* __restrict__ count, int capacity,
                                                     const float* __restrict__ feat_grad, float* __restrict__ k0_grad,
-                                                    uint32_t* __restrict__ touched) {
+                                                    uint8_t* __restrict__ touched) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int m = t >> 4, ch = t & 15;
   int M = min(count[0], capacity);
@@ -258,7 +256,7 @@ __global__ __launch_bounds__(256) void k_k0_pack(const float* __restrict__ pts, 
 }
 
 __global__ __launch_bounds__(256) void k_k0_scatter_packed(SceneDev sc, const float* __restrict__ packed, int capacity,
-                                                           float* __restrict__ k0_grad, uint32_t* __restrict__ touched) {
+                                                           float* __restrict__ k0_grad, uint8_t* __restrict__ touched) {
   const float* __restrict__ shard = packed + (size_t)blockIdx.y * capacity * PP_PACK_LD;
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int m = t >> 4, ch = t & 15;
@@ -289,7 +287,7 @@ extern "C" int pp_k0_pack_samples(const float* pts, const float* feat_grad, cons
 }
 
 extern "C" int pp_k0_scatter_samples(const pp_scene* sc, const float* pts, const int32_t* count, int32_t capacity,
-                                     const float* feat_grad, float* k0_grad_cl, uint32_t* touched, void* stream) {
+                                     const float* feat_grad, float* k0_grad_cl, uint8_t* touched, void* stream) {
   PP_REQUIRE(sc && pts && count && feat_grad && k0_grad_cl, "null pointer");
   PP_REQUIRE(capacity > 0 && sc->k0_dim <= 16, "bad sizes");
   hipLaunchKernelGGL(k_k0_scatter, dim3(pp_div_up(capacity * 16, 256)), dim3(256), 0, pp_stream(stream), pp_scene_dev(sc), pts,
@@ -299,7 +297,7 @@ extern "C" int pp_k0_scatter_samples(const pp_scene* sc, const float* pts, const
 }
 
 extern "C" int pp_k0_scatter_packed(const pp_scene* sc, const float* packed, int32_t n_shards, int32_t capacity,
-                                    float* k0_grad_cl, uint32_t* touched, void* stream) {
+                                    float* k0_grad_cl, uint8_t* touched, void* stream) {
   PP_REQUIRE(sc && packed && k0_grad_cl, "null pointer");
   PP_REQUIRE(capacity > 0 && n_shards > 0 && n_shards <= 65535 && sc->k0_dim <= 12, "bad sizes");
   hipLaunchKernelGGL(k_k0_scatter_packed, dim3(pp_div_up(capacity * 16, 256), n_shards), dim3(256), 0, pp_stream(stream),
@@ -465,7 +463,7 @@ extern "C" int pp_color_feat_bwd(const pp_scene* sc, const float* k0_cl, const f
   PP_CHECK_LAUNCH();
   if (k0_grad_cl) {
     hipLaunchKernelGGL(k_k0_scatter, dim3(pp_div_up(capacity * 16, 256)), dim3(256), 0, st, pp_scene_dev(sc), pts, count,
-                       capacity, feat_grad, k0_grad_cl, (uint32_t*)nullptr);
+                       capacity, feat_grad, k0_grad_cl, (uint8_t*)nullptr);
     PP_CHECK_LAUNCH();
   }
   return PP_OK;

@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void k_grid_tv_adam(const float4* __restrict__
                                                       int x_begin, int x_end, int n_chunks, int chunk_len,
                                                       float tv_scale, float grad_scale, float b1, float b2, float eps,
                                                       float step_size, float inv_sqrt_bc2, float* __restrict__ tv_out,
-                                                      const uint32_t* __restrict__ touched,
-                                                      uint32_t* __restrict__ touched_clear) {
+                                                      const uint8_t* __restrict__ touched,
+                                                      uint8_t* __restrict__ touched_clear) {
   __shared__ float sm[4];
   const int plane = Y * Z * q4;                      // float4 per x-plane
   const int chunk = blockIdx.x % n_chunks;
@@ -66,18 +66,19 @@ __global__ __launch_bounds__(256) void k_grid_tv_adam(const float4* __restrict__
     size_t e = (size_t)xs * plane + i;
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f), pc = p_in[e], pn;
     if (xs > 0) pm = p_in[e - plane];
-    // Sparse gradient: the data-dependent part of the gradient is non-zero only in voxels the scatter marked (~7 % per
-    // step); for the others g == 0 is known without reading it and its zero-fill is a no-op.  The bitmap word of plane
-    // x+1 is fetched one iteration ahead; the OTHER parity's bitmap (consumed last step) is cleared on the way.
+    // Sparse gradient: the data-dependent part of the gradient is non-zero only in voxels the scatter marked (~8 % per
+    // step); for the others g == 0 is known without reading it and its zero-fill is a no-op.  The mark of plane x+1 is
+    // fetched one iteration ahead; the OTHER parity's map (consumed last step) is cleared on the way.
     const int nyz = Y * Z;
     size_t vx = (size_t)xs * nyz + vox;
-    uint32_t wcur = touched ? touched[vx >> 5] : 0xffffffffu, wnext = wcur;
+    uint8_t wcur = touched ? touched[vx] : (uint8_t)1, wnext = wcur;
+    const bool clearer = touched_clear && (i % q4) == 0;
     for (int x = xs; x < xe; ++x, e += plane, vx += nyz) {
       const bool xh = x < X - 1;
       pn = xh ? p_in[e + plane] : pc;
-      if (touched && x + 1 < xe) wnext = touched[(vx + nyz) >> 5];
-      const bool hit = (wcur >> (vx & 31)) & 1u;
-      if (touched_clear && (i % q4) == 0 && (vx & 31) == 0) touched_clear[vx >> 5] = 0u;
+      if (touched && x + 1 < xe) wnext = touched[vx + nyz];
+      const bool hit = wcur != 0;
+      if (clearer) touched_clear[vx] = 0;
       float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
       if (hit) g = ldnt4(grad + e);
       float4 m = ldnt4(m_ + e), v = ldnt4(v_ + e);
@@ -160,8 +161,8 @@ __global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, float*
 extern "C" int pp_grid_tv_adam_step_sparse(const float* p_in, float* p_out, float* grad, float* exp_avg, float* exp_avg_sq,
                                     int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, int32_t x_begin, int32_t x_end,
                                     float tv_scale, float grad_scale, float lr, float beta1, float beta2, float eps,
-                                    int32_t step, float* tv_out, const uint32_t* touched,
-                                            uint32_t* touched_clear, void* stream) {
+                                    int32_t step, float* tv_out, const uint8_t* touched,
+                                            uint8_t* touched_clear, void* stream) {
   PP_REQUIRE(p_in && p_out && grad && exp_avg && exp_avg_sq, "null pointer");
   const int32_t size[3] = {size_x, size_y, size_z};
   PP_REQUIRE(p_in != p_out, "p_in and p_out must be distinct (ping-pong) buffers");

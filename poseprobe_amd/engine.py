@@ -277,9 +277,9 @@ class TrainEngine:
         self.k0_cur = 0
         self.k0_grad, self.k0_m, self.k0_v = (torch.zeros(X, Y, Z, cfg.k0_dim, **f) for _ in range(3))
         self.sdf = torch.zeros(X, Y, Z, **f)
-        # one bit per voxel, two parities: the scatter of step n marks [n & 1], the fused optimiser pass reads it (voxels that
+        # one byte per voxel, two parities: the scatter of step n marks [n & 1], the fused optimiser pass reads it (voxels that
         # were not reached keep a known-zero gradient: no read, no re-zeroing) and clears the other one for step n+1
-        self.k0_touched = torch.zeros(2, (X * Y * Z + 31) // 32, dtype=torch.int32, device=self.dev)
+        self.k0_touched = torch.zeros(2, X * Y * Z, dtype=torch.uint8, device=self.dev)
         self.touch_par = 0
         self._k0_marked = False
         self.flat = FlatParams(self.dev)

@@ -35,6 +35,10 @@ def _i(t, name='tensor'):
     return _ptr(t, torch.int32, name)
 
 
+def _u8(t, name='tensor'):
+    return _ptr(t, torch.uint8, name)
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -160,13 +164,13 @@ def k0_pack_samples(pts, feat_grad, count, capacity, k0_dim, packed):
 
 
 def k0_scatter_packed(sc, packed, n_shards, capacity, k0_grad_cl, touched=None):
-    _lib.call('pp_k0_scatter_packed', ctypes.byref(sc), _f(packed), int(n_shards), capacity, _f(k0_grad_cl), _i(touched),
+    _lib.call('pp_k0_scatter_packed', ctypes.byref(sc), _f(packed), int(n_shards), capacity, _f(k0_grad_cl), _u8(touched),
               _stream())
 
 
 def k0_scatter_samples(sc, pts, count, capacity, feat_grad, k0_grad_cl, touched=None):
     _lib.call('pp_k0_scatter_samples', ctypes.byref(sc), _f(pts), _i(count), capacity, _f(feat_grad), _f(k0_grad_cl),
-              _i(touched), _stream())
+              _u8(touched), _stream())
 
 
 # ------------------------------------------------------------------------------------------- MLPs
@@ -233,7 +237,7 @@ def grid_tv_adam_step_sparse(p_in, p_out, grad, exp_avg, exp_avg_sq, size, chann
                              lr, beta1, beta2, eps, step, tv_out, touched, touched_clear):
     _lib.call('pp_grid_tv_adam_step_sparse', _f(p_in), _f(p_out), _f(grad), _f(exp_avg), _f(exp_avg_sq),
               int(size[0]), int(size[1]), int(size[2]), channels, x_begin, x_end, float(tv_scale), float(grad_scale),
-              float(lr), float(beta1), float(beta2), float(eps), int(step), _f(tv_out), _i(touched), _i(touched_clear),
+              float(lr), float(beta1), float(beta2), float(eps), int(step), _f(tv_out), _u8(touched), _u8(touched_clear),
               _stream())
 
 

@@ -197,8 +197,8 @@ def test_grid_tv_adam_step_matches_oracle(shape):
 
 @pytest.mark.parametrize('shape', [(5, 6, 7), (16, 12, 9), (40, 32, 32)])
 def test_sparse_grid_step_is_bit_identical_to_dense(shape):
-    """pp_grid_tv_adam_step_sparse with the scatter's touched-voxel bitmap == the dense pass, bit for bit: parameters,
-    both moments and the zero-filled gradient (the TV value up to summation order); the previous step's bitmap is cleared."""
+    """pp_grid_tv_adam_step_sparse with the scatter's touched-voxel map == the dense pass, bit for bit: parameters,
+    both moments and the zero-filled gradient (the TV value up to summation order); the previous step's map is cleared."""
     from poseprobe_amd import ops
     X, Y, Z = shape
     C = 12
@@ -210,13 +210,8 @@ def test_sparse_grid_step_is_bit_identical_to_dense(shape):
     grad = torch.zeros(X, Y, Z, C)
     grad[hit] = torch.randn(int(hit.sum()), C, generator=g) * 1e-2
     grad[hit.nonzero()[0][0], hit.nonzero()[0][1], hit.nonzero()[0][2]] = 0.0   # a marked voxel whose gradient is exactly 0
-    nvox = X * Y * Z
-    words = (nvox + 31) // 32
-    bits = torch.zeros(words * 32, dtype=torch.int64)
-    bits[:nvox] = hit.reshape(-1).long()
-    w = (bits.view(words, 32) << torch.arange(32)).sum(1)
-    touched = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).cuda()
-    stale = torch.full((words,), -1, dtype=torch.int32, device='cuda')   # last step's bitmap: must come back all zero
+    touched = hit.reshape(-1).to(torch.uint8).cuda()
+    stale = torch.full((X * Y * Z,), 1, dtype=torch.uint8, device='cuda')   # last step's map: must come back all zero
     outs = []
     for sparse in (False, True):
         gr, m, v = grad.cuda().clone(), m0.clone(), v0.clone()
@@ -234,4 +229,4 @@ def test_sparse_grid_step_is_bit_identical_to_dense(shape):
     # the TV value is a sum of per-block partials combined with float atomics: same terms, unordered
     assert abs(float(outs[0][4]) - float(outs[1][4])) <= 1e-5 * abs(float(outs[0][4]))
     assert float(outs[1][3].abs().max()) == 0
-    assert int(stale.abs().sum()) == 0
+    assert int(stale.sum()) == 0

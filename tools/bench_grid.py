@@ -1,4 +1,4 @@
-"""Isolated A/B of the fused TV+Adam grid pass: dense vs sparse-gradient (touched bitmap).  python tools/bench_grid.py [G] [frac]"""
+"""Isolated A/B of the fused TV+Adam grid pass: dense vs sparse-gradient (touched-voxel byte map).  python tools/bench_grid.py [G] [frac]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,13 +11,10 @@ p = torch.randn(G, G, G, C, device=dev) * 0.1
 po = torch.empty_like(p)
 m, v, g = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
 nvox = G ** 3
-words = (nvox + 31) // 32
 # clustered marks (rays are lines): mark runs of 4 consecutive voxels
 hit = (torch.rand(nvox // 4, device=dev) < frac).repeat_interleave(4)
-bits = hit.view(words, 32).long()
-w = (bits << torch.arange(32, device=dev)).sum(1)
-touched = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
-other = torch.zeros(words, dtype=torch.int32, device=dev)
+touched = hit.to(torch.uint8)
+other = torch.zeros(nvox, dtype=torch.uint8, device=dev)
 tv = torch.zeros(1, device=dev)
 print(f'G={G} marked {float(hit.float().mean()):.3f}')
 def run(sparse, n=20):
