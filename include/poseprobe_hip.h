@@ -148,6 +148,17 @@ int pp_geometry_bwd(const pp_scene* sc, const float* sdf_grid, const float* sdf_
                     const float* g_correction, int32_t accumulate, float* warp_out_grad, float* pts_grad,
                     float* viewdir_grad_s, float* sdf_ab_grad, void* stream);
 
+/* pp_geometry_bwd + pp_loss_samples in one kernel: the four sample-level priors of object_losses (lib/losses.py:6-23) are
+ * evaluated from the recomputed forward, their values accumulated into loss_out[2..5] (as pp_loss_samples does) and
+ * their gradients folded into the backward without the g_grad_deform / g_correction / g_sdf_deform round trip through
+ * HBM.  g_gradient[M,3] = upstream gradient of the normal from the colour features (may be NULL).  Bit-identical to the
+ * two-call sequence. */
+int pp_geometry_bwd_priors(const pp_scene* sc, const float* sdf_grid, const float* sdf_ab, const float* pts,
+                           const float* warp_out, const float* viewdirs, const int32_t* ray_id, const int32_t* count,
+                           int32_t capacity, float inv_s, const float* g_alpha, const float* g_gradient, float w_eikonal,
+                           float w_deform, float loss_scale, int32_t accumulate, float* warp_out_grad, float* pts_grad,
+                           float* viewdir_grad_s, float* sdf_ab_grad, float* loss_out, void* stream);
+
 /* ---------------------------------------------------------------- multi-GPU: k0 gradient exchange at sample granularity
  * (no counterpart in the reference, which has no distributed path; replaces a dense 196 MB reduce-scatter by an
  * all-gather of 64 B per sample).  pp_k0_pack_samples writes packed[capacity][16] = { feat_grad[:, :k0_dim] (12 slots),

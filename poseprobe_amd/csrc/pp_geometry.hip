@@ -156,6 +156,11 @@ __global__ __launch_bounds__(256) void k_geometry_fwd(SceneDev sc, const float* 
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) grad_deform[m * 9 + i * 3 + j] = o.A[i][j];
 }
 
+// PRIORS: the sample-level regularisers of object_losses (lib/losses.py:6-23: eikonal, deformation-Jacobian norm,
+// |correction|, |sdf_deform|) are differentiated right here from the recomputed forward instead of by a separate kernel
+// that writes g_grad_deform / g_correction / g_sdf_deform to HBM first (pp_loss_samples); same expressions, same
+// order of additions, so the two routes are bit-identical.
+template <bool PRIORS>
 __global__ __launch_bounds__(256) void k_geometry_bwd(
     SceneDev sc, const float* __restrict__ grid, const float* __restrict__ sdf_ab, const float* __restrict__ pts,
     const float* __restrict__ warp_out, const float* __restrict__ viewdirs, const int32_t* __restrict__ ray_id,
@@ -163,11 +168,13 @@ __global__ __launch_bounds__(256) void k_geometry_bwd(
     const float* __restrict__ g_gradient, const float* __restrict__ g_sdf_final, const float* __restrict__ g_sdf_deform,
     const float* __restrict__ g_grad_deform, const float* __restrict__ g_correction, int accumulate,
     float* __restrict__ warp_out_grad, float* __restrict__ pts_grad, float* __restrict__ vgrad_s,
-    float* __restrict__ sdf_ab_grad) {
-  __shared__ float red[2][4];
+    float* __restrict__ sdf_ab_grad, float w_eik, float w_dyn, float ls, float* __restrict__ loss_out) {
+  __shared__ float red[6][4];
   int m = blockIdx.x * blockDim.x + threadIdx.x;
   int M = min(count[0], capacity);
   float ga_sum = 0.f, gb_sum = 0.f;
+  float l_eik = 0.f, l_gd = 0.f, l_c = 0.f, l_sd = 0.f;
+  const float invM = M > 0 ? 1.f / (float)M : 0.f;
   if (m < M) {
     MapAB mp = map_ab(sdf_ab);
     float p[3] = {pts[m * 3], pts[m * 3 + 1], pts[m * 3 + 2]};
@@ -196,18 +203,40 @@ __global__ __launch_bounds__(256) void k_geometry_bwd(
     float ic_bar = (nxt_bar - prv_bar) * (dist * 0.5f);
     float cos_bar = (o.cosv < 0.f) ? ic_bar : 0.f;
     float gg[3], vb[3];
+    float eik[3] = {0.f, 0.f, 0.f}, gdef_bar[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, corr_bar = 0.f, sdef_bar = 0.f;
+    if (PRIORS) {
+      const float gn = sqrtf(o.grad[0] * o.grad[0] + o.grad[1] * o.grad[1] + o.grad[2] * o.grad[2]);
+      const float e = gn - 1.f;
+      l_eik = fabsf(e);
+      const float sg = (e > 0.f) ? 1.f : (e < 0.f ? -1.f : 0.f);
+      for (int k = 0; k < 3; ++k) eik[k] = (gn > 0.f) ? ls * w_eik * sg * o.grad[k] / gn * invM : 0.f;
+      for (int i = 0; i < 3; ++i) {
+        const float a0 = o.A[i][0], a1 = o.A[i][1], a2 = o.A[i][2];
+        const float an = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+        l_gd += an;
+        const float sc_ = (an > 0.f) ? ls * w_dyn * invM / (3.f * an) : 0.f;
+        gdef_bar[i][0] = a0 * sc_; gdef_bar[i][1] = a1 * sc_; gdef_bar[i][2] = a2 * sc_;
+      }
+      const float c = wo[3];
+      l_c = fabsf(c);
+      corr_bar = ls * w_dyn * invM * ((c > 0.f) ? 1.f : (c < 0.f ? -1.f : 0.f));
+      const float sd = o.sdf - o.vp;
+      l_sd = fabsf(sd);
+      sdef_bar = ls * w_dyn * invM * ((sd > 0.f) ? 1.f : (sd < 0.f ? -1.f : 0.f));
+    }
     for (int k = 0; k < 3; ++k) {
-      gg[k] = (g_gradient ? g_gradient[m * 3 + k] : 0.f) + cos_bar * v[k];
+      gg[k] = ((g_gradient ? g_gradient[m * 3 + k] : 0.f) + eik[k]) + cos_bar * v[k];
       vb[k] = cos_bar * o.grad[k];
     }
     // ---- grad = A gq + Jc
     float Abar[3][3], gq_bar[3];
     for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) Abar[i][j] = gg[i] * o.gq[j] + (g_grad_deform ? g_grad_deform[m * 9 + i * 3 + j] : 0.f);
+      for (int j = 0; j < 3; ++j)
+        Abar[i][j] = gg[i] * o.gq[j] + (PRIORS ? gdef_bar[i][j] : (g_grad_deform ? g_grad_deform[m * 9 + i * 3 + j] : 0.f));
     for (int j = 0; j < 3; ++j) gq_bar[j] = o.A[0][j] * gg[0] + o.A[1][j] * gg[1] + o.A[2][j] * gg[2];
-    float sd_up = g_sdf_deform ? g_sdf_deform[m] : 0.f;
+    float sd_up = PRIORS ? sdef_bar : (g_sdf_deform ? g_sdf_deform[m] : 0.f);
     float sdf_tot = sdf_bar + sd_up;
-    float c_bar = sdf_tot + (g_correction ? g_correction[m] : 0.f);
+    float c_bar = sdf_tot + (PRIORS ? corr_bar : (g_correction ? g_correction[m] : 0.f));
     float vq_bar = sdf_tot, vp_bar = -sd_up;
     // ---- trilinear backward at q (value + gradient outputs) and p (value only)
     float gu[3], hu[3];
@@ -252,12 +281,22 @@ __global__ __launch_bounds__(256) void k_geometry_bwd(
   gb_sum = pp_wave_sum(gb_sum);
   int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) { red[0][wid] = ga_sum; red[1][wid] = gb_sum; }
+  if (PRIORS) {
+    l_eik = pp_wave_sum(l_eik); l_gd = pp_wave_sum(l_gd); l_c = pp_wave_sum(l_c); l_sd = pp_wave_sum(l_sd);
+    if (lane == 0) { red[2][wid] = l_eik; red[3][wid] = l_gd; red[4][wid] = l_c; red[5][wid] = l_sd; }
+  }
   __syncthreads();
   if (threadIdx.x == 0 && sdf_ab_grad) {
     float a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     float b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     if (a != 0.f) atomicAdd(&sdf_ab_grad[0], a);
     if (b != 0.f) atomicAdd(&sdf_ab_grad[1], b);
+  }
+  if (PRIORS && threadIdx.x == 0 && loss_out && m < M) {       // (m is this block's first sample here)
+    atomicAdd(&loss_out[2], (red[2][0] + red[2][1] + red[2][2] + red[2][3]) * invM);
+    atomicAdd(&loss_out[3], (red[3][0] + red[3][1] + red[3][2] + red[3][3]) * invM / 3.f);
+    atomicAdd(&loss_out[4], (red[4][0] + red[4][1] + red[4][2] + red[4][3]) * invM);
+    atomicAdd(&loss_out[5], (red[5][0] + red[5][1] + red[5][2] + red[5][3]) * invM);
   }
 }
 
@@ -285,10 +324,27 @@ extern "C" int pp_geometry_bwd(const pp_scene* sc, const float* sdf_grid, const 
   PP_REQUIRE(sc && sdf_grid && sdf_ab && pts && warp_out && viewdirs && ray_id && count && warp_out_grad && pts_grad,
              "null pointer");
   PP_REQUIRE(capacity > 0, "capacity<=0");
-  hipLaunchKernelGGL(k_geometry_bwd, dim3(pp_div_up(capacity, 256)), dim3(256), 0, pp_stream(stream), pp_scene_dev(sc),
+  hipLaunchKernelGGL(k_geometry_bwd<false>, dim3(pp_div_up(capacity, 256)), dim3(256), 0, pp_stream(stream), pp_scene_dev(sc),
                      sdf_grid, sdf_ab, pts, warp_out, viewdirs, ray_id, count, capacity, inv_s, g_alpha, g_gradient,
                      g_sdf_final, g_sdf_deform, g_grad_deform, g_correction, accumulate, warp_out_grad, pts_grad,
-                     viewdir_grad_s, sdf_ab_grad);
+                     viewdir_grad_s, sdf_ab_grad, 0.f, 0.f, 0.f, (float*)nullptr);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_geometry_bwd_priors(const pp_scene* sc, const float* sdf_grid, const float* sdf_ab, const float* pts,
+                                      const float* warp_out, const float* viewdirs, const int32_t* ray_id,
+                                      const int32_t* count, int32_t capacity, float inv_s, const float* g_alpha,
+                                      const float* g_gradient, float w_eikonal, float w_deform, float loss_scale,
+                                      int32_t accumulate, float* warp_out_grad, float* pts_grad, float* viewdir_grad_s,
+                                      float* sdf_ab_grad, float* loss_out, void* stream) {
+  PP_REQUIRE(sc && sdf_grid && sdf_ab && pts && warp_out && viewdirs && ray_id && count && warp_out_grad && pts_grad,
+             "null pointer");
+  PP_REQUIRE(capacity > 0, "capacity<=0");
+  hipLaunchKernelGGL(k_geometry_bwd<true>, dim3(pp_div_up(capacity, 256)), dim3(256), 0, pp_stream(stream), pp_scene_dev(sc),
+                     sdf_grid, sdf_ab, pts, warp_out, viewdirs, ray_id, count, capacity, inv_s, g_alpha, g_gradient,
+                     nullptr, nullptr, nullptr, nullptr, accumulate, warp_out_grad, pts_grad, viewdir_grad_s, sdf_ab_grad,
+                     w_eikonal, w_deform, loss_scale, loss_out);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }

@@ -12,24 +12,21 @@ __device__ __forceinline__ float block_sum256(float v, float* sm) {
   return sm[0] + sm[1] + sm[2] + sm[3];
 }
 
-__global__ __launch_bounds__(256) void k_sum(const float* __restrict__ x, int n, float* __restrict__ out) {
-  __shared__ float sm[4];
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
-  s = block_sum256(s, sm);
-  if (threadIdx.x == 0) out[0] = s;
-}
-
 __global__ __launch_bounds__(256) void k_loss_rays(const float* __restrict__ rgbm, const float* __restrict__ alast,
                                                    const float* __restrict__ cw, const float* __restrict__ target,
-                                                   const float* __restrict__ mask_px, const float* __restrict__ mask_sum,
+                                                   const float* __restrict__ mask_px, float* __restrict__ mask_sum,
                                                    int n_rays, float w_main, float w_ent, float w_mask, float ls,
                                                    float* __restrict__ g_rgbm, float* __restrict__ g_alast,
                                                    float* __restrict__ g_cw, float* __restrict__ loss_out) {
   __shared__ float sm[4];
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   float l_mse = 0.f, l_ent = 0.f, l_bce = 0.f;
-  const float msum = mask_sum[0];
+  // number of masked-in pixels of the batch: every block sums the (few KB of) masks itself, in k_sum's order, instead of
+  // waiting for a separate single-block kernel
+  float part = 0.f;
+  for (int i = threadIdx.x; i < n_rays; i += 256) part += mask_px[i];
+  const float msum = block_sum256(part, sm);
+  if (blockIdx.x == 0 && threadIdx.x == 0) mask_sum[0] = msum;
   const float invN = 1.f / (float)n_rays;
   if (r < n_rays) {
     float y = mask_px[r];
@@ -111,7 +108,6 @@ extern "C" int pp_loss_rays(const float* rgb_marched, const float* alphainv_last
              "null pointer");
   PP_REQUIRE(n_rays > 0, "n_rays<=0");
   hipStream_t st = pp_stream(stream);
-  hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, st, mask_px, n_rays, mask_sum);
   hipLaunchKernelGGL(k_loss_rays, dim3(pp_div_up(n_rays, 256)), dim3(256), 0, st, rgb_marched, alphainv_last,
                      cum_weights, target, mask_px, mask_sum, n_rays, w_main, w_entropy, w_mask, loss_scale,
                      g_rgb_marched, g_alphainv_last, g_cum_weights, loss_out);

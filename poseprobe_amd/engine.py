@@ -228,7 +228,7 @@ class RenderCore:
     # -- backward ------------------------------------------------------------------------------------------
     def backward(self, ws, k0_cl, sdf, sdf_ab, rgbnet_p, warp_p, inv_s, pe_w, k0_grad_cl, sdf_ab_grad, rgbnet_grad,
                  warp_grad, g_depth=None, g_weights=None, g_gradient_ext=None, g_sdf_deform=None, g_grad_deform=None,
-                 g_correction=None, g_alpha_ext=None, g_rgb_ext=None, after_k0_grad=None, defer_join=False):
+                 g_correction=None, g_alpha_ext=None, g_rgb_ext=None, after_k0_grad=None, defer_join=False, priors=None):
         """Consumes ws.g_rgbm / ws.g_last / ws.g_cw (+ optional per-sample upstream grads), accumulates parameter
         grads (atomic +=) and leaves d/d ray_pts in ws.g_pts and the per-sample viewdir grads in ws.g_view_s."""
         cfg, sc = self.cfg, self.cfg.pp
@@ -245,11 +245,18 @@ class RenderCore:
                            k0_grad_cl, ws.g_pts, ws.g_gradient, ws.g_view_s)
         if after_k0_grad is not None:
             after_k0_grad()             # multi-GPU: the grid reduce-scatter overlaps the rest of the backward
-        if g_gradient_ext is not None:
-            g_gradient_ext(ws)      # callable adding loss terms into ws.g_gradient etc. (fused step) ...
-        ops.geometry_bwd(sc, sdf, sdf_ab, ws.pts, ws.warp_out, ws.viewdirs, ws.ray_id, ws.count, ws.cap, inv_s,
-                         ws.g_alpha, ws.g_gradient, None, g_sdf_deform, g_grad_deform, g_correction, 1, ws.g_warp_out,
-                         ws.g_pts, ws.g_view_s, sdf_ab_grad)
+        if priors is not None:
+            # fused step: the sample-level priors (eikonal, deformation) are differentiated inside the geometry backward
+            w_eik, w_dyn, ls, loss_out = priors
+            ops.geometry_bwd_priors(sc, sdf, sdf_ab, ws.pts, ws.warp_out, ws.viewdirs, ws.ray_id, ws.count, ws.cap, inv_s,
+                                    ws.g_alpha, ws.g_gradient, w_eik, w_dyn, ls, 1, ws.g_warp_out, ws.g_pts, ws.g_view_s,
+                                    sdf_ab_grad, loss_out)
+        else:
+            if g_gradient_ext is not None:
+                g_gradient_ext(ws)      # callable adding loss terms into ws.g_gradient etc.
+            ops.geometry_bwd(sc, sdf, sdf_ab, ws.pts, ws.warp_out, ws.viewdirs, ws.ray_id, ws.count, ws.cap, inv_s,
+                             ws.g_alpha, ws.g_gradient, None, g_sdf_deform, g_grad_deform, g_correction, 1, ws.g_warp_out,
+                             ws.g_pts, ws.g_view_s, sdf_ab_grad)
         ops.context_join(ctx)           # rgbnet's weight-gradient kernel is done before the next register-hungry kernel
         ops.warp_bwd(warp_p, ws.pts, ws.warp_acts, ws.g_warp_out, ws.count, ws.cap, cfg.out_range, ws.scratch, warp_grad,
                      ws.g_pts, ctx)
@@ -377,10 +384,6 @@ class TrainEngine:
         ops.loss_rays(ws.rgb_marched, ws.alphainv_last, ws.cum_weights, ws.target, ws.mask_px, ws.mask_sum, self.w_main,
                       0.01, self.w_mask, ls, ws.g_rgbm, ws.g_last, ws.g_cw, ws.loss_out)
 
-        def add_sample_losses(w):
-            ops.loss_samples(w.gradient, w.grad_deform, w.warp_out, w.sdf_deform, w.count, w.cap, 1.0, w_dyn, ls,
-                             w.g_gradient, w.g_grad_deform, w.g_corr, w.g_sdf_deform, w.loss_out)
-
         # The k0 scatter is issued from here (not inside colour-feature backward) so that it can mark the voxels it reaches:
         # single GPU = right after the colour-feature backward; multi-GPU "samples" mode = replayed for all ranks' gathered
         # samples at the end of the backward; "zero1" = dense reduce-scatter, no marking (every voxel may be non-zero).
@@ -396,8 +399,7 @@ class TrainEngine:
                 self.dist.start_grid_reduce(self)
         self.core.backward(ws, self.k0_cl, self.sdf, P.view('sdf_ab'), P.view('rgbnet'), P.view('warp'), inv_s, self.pe_w,
                            k0_grad, P.view('sdf_ab', 'grad'), P.view('rgbnet', 'grad'), P.view('warp', 'grad'),
-                           g_gradient_ext=add_sample_losses, g_sdf_deform=ws.g_sdf_deform,
-                           g_grad_deform=ws.g_grad_deform, g_correction=ws.g_corr,
+                           priors=(1.0, w_dyn, ls, ws.loss_out),
                            after_k0_grad=after_k0, defer_join=True)
         ctx = ops.side_context() if self.core.use_side_stream else None
         ops.raygen_select_bwd(sc, ray_idx, self.c2w, self.intr, self.H, self.W, cfg.inverse_y, ws.rays_o, ws.rays_d,

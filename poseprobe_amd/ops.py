@@ -159,6 +159,14 @@ def color_feat_bwd(sc, k0_cl, pts, viewdirs, ray_id, gradient, pe_w, count, capa
               _f(vgrad_s), _stream())
 
 
+def geometry_bwd_priors(sc, sdf_grid, sdf_ab, pts, warp_out, viewdirs, ray_id, count, capacity, inv_s, g_alpha, g_gradient,
+                        w_eikonal, w_deform, loss_scale, accumulate, warp_out_grad, pts_grad, vgrad_s, sdf_ab_grad, loss_out):
+    _lib.call('pp_geometry_bwd_priors', ctypes.byref(sc), _f(sdf_grid), _f(sdf_ab), _f(pts), _f(warp_out), _f(viewdirs),
+              _i(ray_id), _i(count), capacity, float(inv_s), _f(g_alpha), _f(g_gradient), float(w_eikonal), float(w_deform),
+              float(loss_scale), int(accumulate), _f(warp_out_grad), _f(pts_grad), _f(vgrad_s), _f(sdf_ab_grad),
+              _f(loss_out), _stream())
+
+
 def k0_pack_samples(pts, feat_grad, count, capacity, k0_dim, packed):
     _lib.call('pp_k0_pack_samples', _f(pts), _f(feat_grad), _i(count), capacity, int(k0_dim), _f(packed), _stream())
 

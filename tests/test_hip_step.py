@@ -183,3 +183,38 @@ def test_checkpoint_resume_reproduces_the_trajectory(tmp_path):
     missing, unexpected = m.load_state_dict(ck['model_state_dict'], strict=False)
     assert not unexpected, unexpected
     assert torch.equal(m.k0.grid.detach().cpu(), ck['model_state_dict']['k0.grid'])
+
+
+def test_geometry_backward_with_fused_priors_is_bit_identical_to_the_two_kernel_route():
+    """pp_geometry_bwd_priors == pp_loss_samples followed by pp_geometry_bwd (same expressions, same order of additions)."""
+    from poseprobe_amd import ops
+    d = load('forward_g24_s10.npz')
+    eng, cfg = build_engine(d)
+    eng.zero_grads()
+    ray_idx = torch.tensor(d['ray_idx'], dtype=torch.int32, device='cuda')
+    eng.render_and_grads(ray_idx, torch.tensor(d['jitter'], device='cuda'), int(d['global_step']))
+    ws, sc, P = eng.ws, cfg.pp, eng.flat
+    M = int(ws.count.item())
+    inv_s = float(np.float32(1.0) / np.float32(cfg.s_val(int(d['global_step']))))
+    w_dyn, ls = 0.037, 0.1
+    outs = []
+    for fused in (False, True):
+        gwo = torch.zeros_like(ws.g_warp_out); gp = torch.zeros_like(ws.g_pts); gv = torch.zeros_like(ws.g_view_s)
+        gab = torch.zeros(2, device='cuda'); lo = torch.zeros(8, device='cuda')
+        gg = ws.g_gradient.clone()
+        if fused:
+            ops.geometry_bwd_priors(sc, eng.sdf, P.view('sdf_ab'), ws.pts, ws.warp_out, ws.viewdirs, ws.ray_id, ws.count,
+                                    ws.cap, inv_s, ws.g_alpha, gg, 1.0, w_dyn, ls, 1, gwo, gp, gv, gab, lo)
+        else:
+            gd, gc, gs = torch.zeros_like(ws.g_grad_deform), torch.zeros_like(ws.g_corr), torch.zeros_like(ws.g_sdf_deform)
+            ops.loss_samples(ws.gradient, ws.grad_deform, ws.warp_out, ws.sdf_deform, ws.count, ws.cap, 1.0, w_dyn, ls, gg,
+                             gd, gc, gs, lo)
+            ops.geometry_bwd(sc, eng.sdf, P.view('sdf_ab'), ws.pts, ws.warp_out, ws.viewdirs, ws.ray_id, ws.count, ws.cap,
+                             inv_s, ws.g_alpha, gg, None, gs, gd, gc, 1, gwo, gp, gv, gab)
+        torch.cuda.synchronize()
+        outs.append((gwo[:M].cpu(), gp[:M].cpu(), gv[:M].cpu(), gab.cpu(), lo.cpu()))
+    for a, b, name in zip(outs[0][:3], outs[1][:3], ('warp_out_grad', 'pts_grad', 'viewdir_grad')):
+        assert torch.equal(a, b), name
+    # block partials meet in float atomics (unordered): scalars up to summation order
+    assert torch.allclose(outs[0][3], outs[1][3], rtol=1e-5, atol=1e-9)
+    assert torch.allclose(outs[0][4], outs[1][4], rtol=1e-5, atol=1e-9) and float(outs[1][4][2:6].abs().sum()) > 0
