@@ -15,8 +15,10 @@
 #define WPF_W4 (WPF_B3 + 128)
 #define WPF_B4 (WPF_W4 + 4 * 128)
 
-// persistent grid of the fused kernels: one work-group per CU (weights stationary in ~200 registers per lane)
-#define PP_FUSED_WGS 256
+// persistent grid of the fused kernels: one work-group per CU (weights stationary in ~200 registers per lane, LDS 70-156 KB);
+// the CU count of the current device is queried once (256 on an MI355X in SPX mode)
+int pp_fused_wgs();
+#define PP_FUSED_WGS pp_fused_wgs()
 
 int pp_launch_warp_fused_fwd(const float* params, const float* pts, const int32_t* count, int capacity, float out_range,
                              float* acts, float* out, hipStream_t st);

@@ -26,6 +26,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDA 132                 // LDS row stride of an activation tile (floats): 16-B aligned, 4-bank skew per row
 #define TILE_ROWS 64
 
+int pp_fused_wgs() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      n = cus;
+    else
+      n = 256;
+  }
+  return n;
+}
+
 namespace {
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2]) {
