@@ -715,9 +715,11 @@ __global__ __launch_bounds__(256) void k_wgrad_chain(WgradLayer LA, WgradLayer L
   // adjacent tiles, so only the very last pair can contain an empty tile (rows clamped, Y zeroed by fix_tail);
   // straight-line control flow keeps the 192 accumulator registers pinned across the hand-scheduled blocks.
   const int npairs = (ntiles + 1) >> 1;
-  wgrad_issue<128>(LA, blockIdx.x * 2 * TILE_ROWS, R, Yb0, Xb0, wid, lane);
+  // Tiles are walked from the END of the row range: the backward-data kernel that just ran wrote Ybar front to back, so its
+  // most recent output is what the 256 MB Infinity Cache still holds.
+  wgrad_issue<128>(LA, (npairs - 1 - (int)blockIdx.x) * 2 * TILE_ROWS, R, Yb0, Xb0, wid, lane);
   for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
-    const int r0 = pair * 2 * TILE_ROWS;
+    const int r0 = (npairs - 1 - pair) * 2 * TILE_ROWS;
     const int r1 = r0 + TILE_ROWS;
     const int t2 = pair + gridDim.x;
     PP_WAIT_VMEM(); __syncthreads();
@@ -737,7 +739,7 @@ __global__ __launch_bounds__(256) void k_wgrad_chain(WgradLayer LA, WgradLayer L
     wgrad_step<KXC, 128>(true, LC, r1, R, Yb1, Xb1, Yb0, Xb0, accB, wid, lane);
     PP_WAIT_VMEM(); __syncthreads();
     fix_tail(r1, Yb1);
-    wgrad_step<128, KXC>(t2 < npairs, LA, t2 * 2 * TILE_ROWS, R, Yb0, Xb0, Yb1, Xb1, accC, wid, lane);
+    wgrad_step<128, KXC>(t2 < npairs, LA, (npairs - 1 - t2) * 2 * TILE_ROWS, R, Yb0, Xb0, Yb1, Xb1, accC, wid, lane);
   }
   wgrad_flush<128>(LA.Wbar, accA, wr, wc, l31, lh);
   wgrad_flush<128>(LB.Wbar, accB, wr, wc, l31, lh);
