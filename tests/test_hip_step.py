@@ -218,3 +218,31 @@ def test_geometry_backward_with_fused_priors_is_bit_identical_to_the_two_kernel_
     # block partials meet in float atomics (unordered): scalars up to summation order
     assert torch.allclose(outs[0][3], outs[1][3], rtol=1e-5, atol=1e-9)
     assert torch.allclose(outs[0][4], outs[1][4], rtol=1e-5, atol=1e-9) and float(outs[1][4][2:6].abs().sum()) > 0
+
+
+def test_step_with_no_sample_inside_the_box_is_finite_and_leaves_the_data_gradients_zero():
+    """Degenerate batch: every camera looks away from the bounding box, so the sampler keeps M = 0 samples.  Every kernel
+    of the fused step must cope with an empty sample list (the reference would raise on empty tensors here): losses
+    finite, MLP / pose / alpha-beta gradients exactly zero, the colour grid only sees its TV term."""
+    d = load('forward_g8_s10.npz')
+    eng, cfg = build_engine(d)
+    w2c = torch.tensor(d['w2c_init']).clone()
+    w2c[:, :3, :3] = -w2c[:, :3, :3]            # point the optical axes the other way (and mirror the image plane)
+    w2c[:, :3, 3] = -w2c[:, :3, 3]
+    eng.w2c_init.copy_(w2c.cuda())
+    eng.zero_grads()
+    k0_before = eng.k0_cl.clone()
+    ray_idx = torch.tensor(d['ray_idx'], dtype=torch.int32, device='cuda')
+    eng.train_step(ray_idx, torch.tensor(d['jitter'], device='cuda'), int(d['global_step']))
+    torch.cuda.synchronize()
+    assert int(eng.ws.count.item()) == 0
+    L = eng.losses()
+    assert all(np.isfinite(v) for v in L.values()), L
+    assert L['grad_constraint'] == 0 and L['sdf_deform_constraint'] == 0
+    assert bool(torch.isfinite(eng.k0_cl).all()) and bool(torch.isfinite(eng.flat.data).all()) and bool(torch.isfinite(eng.se3).all())
+    # Adam with zero data gradient: the MLP parameters do not move, the grid moves by its TV term only (|step| <= lr)
+    P = params_from_npz(d)
+    from poseprobe_amd.engine import unpack_rgbnet
+    assert torch.equal(unpack_rgbnet(eng.flat.view('rgbnet'))[1][0].cpu(), P['rgbnet'][1][0])
+    assert float((eng.k0_cl - k0_before).abs().max()) <= 0.1 * 1.0001
+    assert int(eng.k0_touched.sum()) == 0
