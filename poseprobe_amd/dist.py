@@ -78,8 +78,9 @@ class DistContext:
         else:
             dist.all_gather_into_tensor(grid, grid[xb:xe], group=self.group)
 
-    def all_reduce_small(self, tensors):
-        """One bucketed all-reduce (SUM) over a list of small tensors."""
+    def all_reduce_small(self, tensors, async_op=False):
+        """One bucketed all-reduce (SUM) over a list of small tensors.  async_op=True: the reduced values are copied back by
+        wait_small() - the engine calls it after the dense grid pass, so the (latency-bound) collective hides behind it."""
         n = sum(t.numel() for t in tensors)
         if self._bucket is None or self._bucket.numel() != n or self._bucket.device != tensors[0].device:
             self._bucket = torch.empty(n, dtype=tensors[0].dtype, device=tensors[0].device)
@@ -87,7 +88,19 @@ class DistContext:
         for t in tensors:
             self._bucket[o:o + t.numel()].copy_(t.reshape(-1))
             o += t.numel()
-        dist.all_reduce(self._bucket, group=self.group)
+        work = dist.all_reduce(self._bucket, group=self.group, async_op=async_op)
+        self._small = (work, tensors)
+        if not async_op:
+            self.wait_small()
+
+    def wait_small(self):
+        pending = getattr(self, '_small', None)
+        if pending is None:
+            return
+        work, tensors = pending
+        self._small = None
+        if work is not None:
+            work.wait()
         o = 0
         for t in tensors:
             t.copy_(self._bucket[o:o + t.numel()].view_as(t))
@@ -144,7 +157,7 @@ class DistContext:
             ops.k0_scatter_packed(eng.cfg.pp, self._gathered, self.world, eng.ws.cap, eng.k0_grad,
                                   eng.k0_touched[eng.touch_par])
             eng.x_slab = (0, X)
-            self.all_reduce_small([eng.flat.grad, eng.se3_grad])
+            self.all_reduce_small([eng.flat.grad, eng.se3_grad], async_op=True)     # finished by wait_small() after the grid pass
             eng.grad_scale = 1.0 / self.world
             return
         work = getattr(self, '_grid_work', None)
@@ -162,7 +175,7 @@ class DistContext:
             eng.x_slab = (xb, xe)
         else:
             eng.x_slab = (0, X)
-        self.all_reduce_small([eng.flat.grad, eng.se3_grad])
+        self.all_reduce_small([eng.flat.grad, eng.se3_grad], async_op=True)
         eng.grad_scale = 1.0 / self.world
 
     def gather_parameters(self, eng):

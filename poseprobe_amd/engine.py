@@ -426,6 +426,8 @@ class TrainEngine:
         for k in self.lr:                       # per-step exponential decay precedes the step (recon_scene.py:742-768)
             self.lr[k] *= self.decay
         self._k0_step(self.lr['k0'], self.n_step, grad_scale)
+        if self.dist is not None:
+            self.dist.wait_small()          # the small all-reduce (MLP / alpha-beta / pose gradients) ran beside the grid pass
         ops.adam_flat(self.flat.data, self.flat.grad, self.flat.m, self.flat.v, self.seg_end, self.seg_lr, grad_scale, 0.9,
                       0.99, 1e-8, self.n_step, 1)
         if optimize_pose:
