@@ -129,6 +129,13 @@ def _worker_samples(rank, world, port, q):
     t = torch.full((4,), float(rank))
     ctx.broadcast_state([t])
     ok = ok and bool((t == 0).all())
+    # the small bucket in its asynchronous form: values are only valid after wait_small()
+    a, b = torch.full((5,), float(rank + 1)), torch.full((2, 3), 10.0 * (rank + 1))
+    ctx.all_reduce_small([a, b], async_op=True)
+    ctx.wait_small()
+    tot = sum(range(1, world + 1))
+    ok = ok and bool((a == tot).all()) and bool((b == 10.0 * tot).all())
+    ctx.wait_small()                                             # idempotent
     if rank == 0:
         q.put(bool(ok))
     dist.destroy_process_group()
