@@ -169,24 +169,6 @@ __device__ __forceinline__ void mask_epilogue(const f32x16 (&acc)[2], const floa
   else mask_epilogue_impl<false, TOGLOBAL>(acc, mk, r0, R, col, lh, C, Anext, bsum);
 }
 
-// primal-row activations (one per sample) that gate the 8 samples a lane owns in the accumulator layout
-template <bool FULL>
-__device__ __forceinline__ void load_masks_impl(float (&mk)[2][4], const float* __restrict__ X, int r0, int R, int col, int lh) {
-  const float* __restrict__ Xt = X + (size_t)r0 * 128;
-  const unsigned lane_off = (unsigned)(4 * lh) * 128u + (unsigned)col;
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = t * 32 + 8 * q;
-      mk[t][q] = (FULL || r0 + row + 4 * lh < R) ? Xt[lane_off + (unsigned)(row * 128)] : 0.f;
-    }
-}
-__device__ __forceinline__ void load_masks(float (&mk)[2][4], const float* __restrict__ X, int r0, int R, int col, int lh) {
-  if (r0 + TILE_ROWS <= R) load_masks_impl<true>(mk, X, r0, R, col, lh);
-  else load_masks_impl<false>(mk, X, r0, R, col, lh);
-}
-
 template <bool B> struct BoolC { static constexpr bool value = B; };
 // run `f` with a compile-time copy of a wave-uniform condition (fast path without per-element guards)
 #define PP_WITH_FULL(cond, f) do { if (cond) f(BoolC<true>{}); else f(BoolC<false>{}); } while (0)
@@ -227,7 +209,7 @@ __global__ __launch_bounds__(256) void k_warp_fused_fwd(const float* __restrict_
   // and consumed right after the first MFMA block, when the stores before it have long retired.
   __shared__ float Ps[48];
   float pnext = 0.f;
-  if (tid < 48 && blockIdx.x * 48 + tid < M * 3) pnext = pts[blockIdx.x * 48 + tid];
+  if (tid < 48 && (int)blockIdx.x * 48 + tid < M * 3) pnext = pts[blockIdx.x * 48 + tid];
   if (tid < 48) Ps[tid] = pnext;
   // every prologue load (weights!) has landed before the loop: otherwise the first in-loop use of a loop-invariant
   // register carries a conservative vmcnt(0) that drains the activation stores on every iteration
