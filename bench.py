@@ -54,8 +54,11 @@ def init_engine_params(eng, cfg, seed):
 
 
 def cpu_baseline(G, H, W, V, n_rand, views, budget_s=20.0):
-    """Oracle train step on the host cores: bounded sample of the SAME workload."""
+    """Oracle train step on the host cores: bounded sample of the SAME workload.  torch-CPU stops scaling (and then
+    degrades: 128 threads are 3x slower than 32 for these op sizes) beyond ~32 threads, so at most 32 are used."""
     from oracle import voxurf_oracle as O
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(min(32, threads_before))
     rs = syn.range_shape()
     scene = O.Scene(syn.XYZ_MIN, syn.XYZ_MAX, G ** 3, output_range=float(rs.max()), rect_size=rs.tolist())
     P = O.init_params(scene, seed=3)
@@ -73,7 +76,9 @@ def cpu_baseline(G, H, W, V, n_rand, views, budget_s=20.0):
         if s >= 2 and (time.time() - t_start > budget_s or s >= 12):
             break
     t = float(np.median(times[1:])) if len(times) > 1 else times[0]
-    return {'value': n_rand / t, 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+    used = torch.get_num_threads()
+    torch.set_num_threads(threads_before)
+    return {'value': n_rand / t, 'unit': 'rays/s', 'cores': used, 'kind': 'port',
             'sample': f'{len(times)} oracle train steps (torch-CPU fp32, {n_rand} rays, {G}^3 grid, first step dropped), '
                       f'median {t:.3f} s/step'}
 
