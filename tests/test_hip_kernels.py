@@ -230,3 +230,31 @@ def test_sparse_grid_step_is_bit_identical_to_dense(shape):
     assert abs(float(outs[0][4]) - float(outs[1][4])) <= 1e-5 * abs(float(outs[0][4]))
     assert float(outs[1][3].abs().max()) == 0
     assert int(stale.sum()) == 0
+
+
+def test_packed_sample_exchange_replays_the_local_scatter():
+    """pp_k0_pack_samples + pp_k0_scatter_packed (the multi-GPU exchange format, two shards with ragged counts and stale rows
+    past the count) == pp_k0_scatter_samples applied shard by shard; marks included."""
+    from poseprobe_amd import ops
+    cfg = _cfg(12)
+    sc = cfg.pp
+    X, Y, Z = cfg.world_size
+    cap, C = 300, 12
+    g = torch.Generator().manual_seed(9)
+    lo, hi = torch.tensor(cfg.xyz_min), torch.tensor(cfg.xyz_max)
+    shards = []
+    for M in (257, 120):
+        pts = (lo + (hi - lo) * (torch.rand(cap, 3, generator=g) * 1.1 - 0.05)).float().cuda()    # some land outside the box
+        gf = torch.zeros(cap, 64); gf[:, :57] = torch.randn(cap, 57, generator=g)
+        shards.append((pts, gf.cuda(), torch.tensor([M], dtype=torch.int32, device='cuda')))
+    ref = torch.zeros(X, Y, Z, C, device='cuda'); ref_t = torch.zeros(X * Y * Z, dtype=torch.uint8, device='cuda')
+    packed = torch.full((2, cap, 16), 77.0, device='cuda')                                         # stale content everywhere
+    for r, (pts, gf, cnt) in enumerate(shards):
+        ops.k0_scatter_samples(sc, pts, cnt, cap, gf, ref, ref_t)
+        ops.k0_pack_samples(pts, gf, cnt, cap, C, packed[r])
+    got = torch.zeros_like(ref); got_t = torch.zeros_like(ref_t)
+    ops.k0_scatter_packed(sc, packed, 2, cap, got, got_t)
+    torch.cuda.synchronize()
+    assert int(packed[0, 0, 15:16].view(torch.int32)[0]) == 257 and int(packed[1, 0, 15:16].view(torch.int32)[0]) == 120
+    assert torch.equal(got_t, ref_t) and int(ref_t.sum()) > 0
+    assert_close(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6, name='replayed scatter')   # unordered atomics

@@ -61,3 +61,25 @@ def test_schedules_match_the_oracle():
         assert cfg.s_val(gs) == O.s_val_at(scene, gs)
         assert dynamic_weight(1e-1, 1e-3, gs, 10000) == O.dynamic_weight(1e-1, 1e-3, gs, 10000)
     assert math.isclose(dynamic_weight(1e-1, 1e-3, 10000, 10000), 1e-3)
+
+
+def test_committed_bench_record_follows_the_contract():
+    """profiles/r01_end_bench.json is the line `python bench.py` printed on the MI355X: keys and types of the driver's
+    contract (metric, value, unit, n_gpus, steps, warmup, ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data,
+    config.workload) plus the `roofline` and `cpu_baseline` objects."""
+    import json
+    import os
+    from tests.conftest import ROOT
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_end_bench.json')))
+    for k, t in (('metric', str), ('value', float), ('unit', str), ('n_gpus', int), ('steps', int), ('warmup', int),
+                 ('ms_per_step', float), ('higher_is_better', bool), ('scaling', str), ('dtype', str), ('data', str)):
+        assert isinstance(d[k], t), k
+    assert d['vs_baseline'] is None and d['scaling'] == 'weak' and d['higher_is_better'] is True
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['frac'] < 1
+    assert r['traffic'] is None or r['traffic'] >= 0.9 * r['algorithmic_bytes_per_launch']
+    c = d['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and isinstance(c['sample'], str)
+    assert abs(d['value'] - 1024 * d['n_gpus'] / (d['ms_per_step'] * 1e-3)) < 1e-3 * d['value']
