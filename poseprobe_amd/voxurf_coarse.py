@@ -492,7 +492,13 @@ class Voxurf(torch.nn.Module):
         out = self.forward(rays_o, rays_d, viewdirs, use_deform=use_deform, global_step=global_step, **render_kwargs)
         nrm = rays_d.norm(dim=-1)
         n_step = out['_n_step']                                            # = sum_i w_i step_i (differentiable)
-        depth = out['_t_min'][..., None] + n_step[..., None] / nrm[..., None]
+        # the entry distance itself depends on the ray (slab test, voxurf_coarse.py:701-705): restated in torch so that its
+        # derivative reaches the pose; values are those of out['_t_min']
+        vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+        lo, hi = self.xyz_min.to(rays_o.device), self.xyz_max.to(rays_o.device)
+        t_min = torch.minimum((hi - rays_o) / vec, (lo - rays_o) / vec).amax(-1).clamp(min=render_kwargs['near'],
+                                                                                           max=render_kwargs['far'])
+        depth = t_min[..., None] + n_step[..., None] / nrm[..., None]
         mask = n_step > 0.
         if keep_dim:
             return rays_o + rays_d * depth, mask, depth
