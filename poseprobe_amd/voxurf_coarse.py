@@ -484,6 +484,13 @@ class Voxurf(torch.nn.Module):
         pts, mask, sdf_d = self._query_crossing(rays_o, rays_d, global_step, False, False, render_kwargs)
         return self._query_finish(rays_o, rays_d, pts, mask, sdf_d, keep_dim, return_depth)
 
+    def _entry_distance(self, rays_o, rays_d, near, far):
+        """t_min of the slab test (voxurf_coarse.py:701-705) restated in torch: the kernels produce the same values in the
+        sampler, this copy exists so that d t_min / d ray reaches the pose wherever t_min enters an output explicitly."""
+        vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+        lo, hi = self.xyz_min.to(rays_o.device), self.xyz_max.to(rays_o.device)
+        return torch.minimum((hi - rays_o) / vec, (lo - rays_o) / vec).amax(-1).clamp(min=near, max=far)
+
     def query_sdf_point_wocuda_render(self, rays_o, rays_d, global_step=None, keep_dim=False, return_depth=False,
                                       use_deform=True, **render_kwargs):
         """voxurf_coarse.py:839-920: expected depth from the rendering weights; differentiable (pose, warp, grid) because
@@ -492,12 +499,7 @@ class Voxurf(torch.nn.Module):
         out = self.forward(rays_o, rays_d, viewdirs, use_deform=use_deform, global_step=global_step, **render_kwargs)
         nrm = rays_d.norm(dim=-1)
         n_step = out['_n_step']                                            # = sum_i w_i step_i (differentiable)
-        # the entry distance itself depends on the ray (slab test, voxurf_coarse.py:701-705): restated in torch so that its
-        # derivative reaches the pose; values are those of out['_t_min']
-        vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
-        lo, hi = self.xyz_min.to(rays_o.device), self.xyz_max.to(rays_o.device)
-        t_min = torch.minimum((hi - rays_o) / vec, (lo - rays_o) / vec).amax(-1).clamp(min=render_kwargs['near'],
-                                                                                           max=render_kwargs['far'])
+        t_min = self._entry_distance(rays_o, rays_d, render_kwargs['near'], render_kwargs['far'])
         depth = t_min[..., None] + n_step[..., None] / nrm[..., None]
         mask = n_step > 0.
         if keep_dim:
@@ -539,6 +541,9 @@ class Voxurf(torch.nn.Module):
                                    *self._mlp_tensors())
         (rgb_marched, alphainv_last, cum_weights, weights, alpha, rgb, depth, gradient, sdf_deform, grad_deform,
          correction, n_step) = outs
+        if torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad):
+            # same value, but with the explicit t_min / |d| term differentiable w.r.t. the ray (voxurf_coarse.py:1057)
+            depth = self._entry_distance(rays_o, rays_d, render_kwargs['near'], render_kwargs['far']) / rays_d.norm(dim=-1) + n_step
         normal_marched = None
         if render_kwargs.get('render_grad', False):
             normal = gradient.detach() / (gradient.detach().norm(2, -1, keepdim=True) + 1e-6)

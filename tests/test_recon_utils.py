@@ -54,3 +54,29 @@ def test_project_error_matches_reference(use_deform):
     if use_deform:          # the rendered-depth query is differentiable end to end (pose gradient through the HIP backward)
         (err + near).backward()
         assert_close(se3.grad.cpu().numpy(), d['g_se3_deform'], rtol=2e-3, atol=1e-4, scaled=1e-3, name='d/d se3')
+
+
+@pytest.mark.gpu
+def test_training_depth_is_differentiable_through_the_entry_distance():
+    """`depth = t_min / |d| + sum(w * step)` of the training forward (lib/voxurf_coarse.py:1050-1058): value and
+    d(sum depth)/d(se3) against the reference - the t_min term reaches the pose explicitly, not only through the samples."""
+    from poseprobe_amd import camera
+    from poseprobe_amd import voxurf_coarse as Model
+    from tests.test_hip_dropin import make_model
+    d = load('reproj_g24.npz')
+    m = make_model(d)
+    dev = 'cuda'
+    H, W = int(d['H']), int(d['W'])
+    se3 = torch.tensor(d['se3'], device=dev, requires_grad=True)
+    init = torch.tensor(d['w2c_init'], device=dev)
+    w2c = torch.cat([init[:1], camera.pose.compose([camera.lie.se3_to_SE3(se3), init])[1:]], 0)
+    c2w = camera.pose.invert(w2c)
+    idx = torch.tensor(d['depth_ray_idx'], device=dev)
+    zeros = torch.zeros(3, H, W, 3, device=dev)
+    _, _, ro, rd, vd = Model.select_training_rays(idx, zeros, torch.ones(3, H, W, 1, device=dev), c2w,
+                                                  np.array([[H, W]] * 3), torch.tensor(d['Ks'], device=dev))
+    out = m(ro, rd, vd, use_deform=True, global_step=50, near=0.24, far=4.8, bg=0, stepsize=1.5, inverse_y=True, flip_x=False,
+            flip_y=False, jitter=torch.tensor(d['depth_jitter']))
+    assert_close(out['depth'].detach().cpu().numpy(), d['depth_vals'], rtol=1e-4, atol=1e-5, name='depth')
+    out['depth'].sum().backward()
+    assert_close(se3.grad.cpu().numpy(), d['depth_g_se3'], rtol=2e-3, atol=1e-4, scaled=1e-3, name='d depth / d se3')
