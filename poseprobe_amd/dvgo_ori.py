@@ -98,12 +98,12 @@ class _DVGORender(torch.autograd.Function):
         ctx.model, ctx.st = model, st
         ctx.save_for_backward(density, k0, dens, exp_d, alpha, w, T, last, i_end, sel, feat, params, acts, rgb, rgb_eff,
                               pre, *([k0_raw] if k0_raw is not None else []))
-        ctx.mark_non_differentiable(w, alpha, rgb_eff, sel)
-        return pre.clamp(0, 1), last.clone(), depth, w, alpha, rgb_eff, sel
+        ctx.mark_non_differentiable(sel)
+        return pre.clamp(0, 1), last.clone(), depth, w.clone(), alpha.clone(), rgb_eff.clone(), sel
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_rgbm, g_last, g_depth, *_):
+    def backward(ctx, g_rgbm, g_last, g_depth, g_w, g_alpha_up, g_rgb_up, _g_sel):
         model, st = ctx.model, ctx.st
         cfg, sc = st['cfg'], st['cfg'].pp
         (density, k0, dens, exp_d, alpha, w, T, last, i_end, sel, feat, params, acts, rgb, rgb_eff, pre, *rest) = ctx.saved_tensors
@@ -114,9 +114,11 @@ class _DVGORender(torch.autograd.Function):
         g_acc = (g_rgbm * ((pre >= 0) & (pre <= 1))).contiguous()
         g_last_t = (g_last + cfg.bg * g_acc.sum(-1) + cfg.far * g_depth).contiguous()
         g_alpha, g_rgb = torch.empty(cap, **f), torch.empty(cap, 3, **f)
+        # upstream gradients of the per-sample outputs (weights, raw_alpha, raw_rgb) enter next to the compositing terms
         ops.march_bwd(alpha, rgb_eff, st['dist_o'], w, T, last, st['ray_start'], i_end, N, 0.0, None, g_acc, None, g_last_t,
-                      g_depth.contiguous(), None, g_alpha, g_rgb)
-        g_rgb = g_rgb * sel.bool()[:, None]
+                      g_depth.contiguous(), g_w.contiguous().float(), g_alpha, g_rgb)
+        g_alpha = g_alpha + g_alpha_up
+        g_rgb = (g_rgb + g_rgb_up) * sel.bool()[:, None]
         n_gemm = model.rgbnet_kwargs['rgbnet_depth'] - 1
         scratch = torch.empty(3 * cap * 128 + 16384, **f)
         pgrad = torch.zeros_like(params)

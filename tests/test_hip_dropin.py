@@ -258,3 +258,35 @@ def test_reference_style_training_loop_with_hip_adam(tmp_path):
     m2 = utils.load_model(Model.Voxurf, path)
     for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a.cpu(), b.cpu()), k
+
+
+def test_directvoxgo_twin_backward_is_complete():
+    """Random linear functional over the twin's differentiable outputs (pixels, alphainv_cum, weights, raw_alpha, depth):
+    value and the gradients of density, k0 and rgbnet against the reference."""
+    from poseprobe_amd import synthetic as syn
+    from poseprobe_amd.dvgo_ori import DirectVoxGO
+    d = load('dvgo_g16.npz')
+    G = int(d['G'])
+    m = DirectVoxGO(syn.XYZ_MIN, syn.XYZ_MAX, num_voxels=G ** 3, num_voxels_base=G ** 3, alpha_init=1e-2, rgbnet_dim=12,
+                    rgbnet_direct=True, rgbnet_depth=3, rgbnet_width=128, posbase_pe=5, viewbase_pe=4, fast_color_thres=1e-4)
+    sd = m.state_dict()
+    sd['density'], sd['k0'] = torch.tensor(d['density']), torch.tensor(d['k0'])
+    for li, key in enumerate(['rgbnet.0', 'rgbnet.2.0', 'rgbnet.3']):
+        sd[key + '.weight'], sd[key + '.bias'] = torch.tensor(d[f'rgbnet.{li}.weight']), torch.tensor(d[f'rgbnet.{li}.bias'])
+    m.load_state_dict(sd)
+    m = m.cuda()
+    ro, rd, vd = (torch.tensor(d[k]).cuda() for k in ('rays_o', 'rays_d', 'viewdirs'))
+    out = m(ro, rd, vd, global_step=5, near=0.24, far=4.8, bg=1, stepsize=0.5, inverse_y=True, flip_x=False, flip_y=False,
+            jitter=torch.tensor(d['jitter']))
+    total = 0.
+    for k in ('alphainv_cum', 'weights', 'rgb_marched', 'raw_alpha', 'depth'):
+        total = total + (torch.tensor(d['lf_coef_' + k]).cuda() * out[k]).sum()
+    c = lambda t: t.detach().cpu().numpy()
+    assert_close(c(total), d['lf_value'], rtol=2e-4, atol=1e-3, name='functional value')
+    total.backward()
+    tol = dict(rtol=2e-3, atol=1e-6, scaled=1e-3)
+    assert_close(c(m.density.grad), d['lf_g_density'], name='g.density', **tol)
+    assert_close(c(m.k0.grad), d['lf_g_k0'], name='g.k0', **tol)
+    for li, lin in enumerate([m.rgbnet[0], m.rgbnet[2][0], m.rgbnet[3]]):
+        assert_close(c(lin.weight.grad), d[f'lf_g.rgbnet.{li}.weight'], name=f'g.rgbnet{li}.W', **tol)
+        assert_close(c(lin.bias.grad), d[f'lf_g.rgbnet.{li}.bias'], name=f'g.rgbnet{li}.b', **tol)
