@@ -340,6 +340,40 @@ int pp_march_dvgo_fwd(const float* alpha, const float* rgb, const float* step_w,
                       int32_t n_rays, float* weights, float* T, float* alphainv_last, int32_t* i_end,
                       float* rgb_acc, float* cum_weights, float* depth_acc, void* stream);
 
+/* ---------------------------------------------------------------- scene branch: NeRF MLP + compositing
+ * (lib/bg_nerf/source/models/frequency_nerf.py).  Replaces NeRF.forward_samples (:268-288 -> compute_raw_density :149-170,
+ * forward :172-227, positional_encoding :239-266 with FrequencyEmbedder :42-69) and NeRF.composite (:290-343) for the
+ * default architecture (default_config.py:90-105): L_3D = 10, L_view = 4 with raw coordinates, 8 x 256 feature layers,
+ * skip at 4, softplus density, 283 -> 128 -> 3 colour head.
+ *
+ * Parameter block (floats), offsets from pp_nerf_layout(offsets[23]) = {W0,b0,...,W7,b7,wd,bd,R0,br0,R1,br1,total}:
+ *   W0[256][64] (63 used) | W1..W3[256][256] | W4[256][320] (features 0..255, encoding 256..318) | W5,W6 |
+ *   wd[256] W7[256][256] | bd b7[256] = the reference's last layer [257][256] / [257] stored contiguously (row 0 = density) |
+ *   R0[128][288] (features 0..255, view encoding 256..282) | R1[3][128].
+ * Rays: center[R,3], ray[R,3] (un-normalised), depth[R,S]; sample m = r * S + s.  bands[14] (device) = BARF's coarse-to-fine
+ * weights of the 10 point bands then the 4 view bands (ones without a schedule).  count: device int32 holding R * S.
+ * Workspaces in floats from pp_nerf_workspace(R * S, R, &acts, &scratch). */
+int pp_nerf_layout(int64_t* offsets);
+int pp_nerf_workspace(int64_t n_samples, int64_t n_rays, int64_t* acts_floats, int64_t* scratch_floats);
+int pp_nerf_fwd(const float* params, const float* center, const float* ray, const float* depth, const float* bands,
+                const int32_t* count, int32_t n_rays, int32_t n_samples, float* acts, float* rgb_samples,
+                float* density_samples, void* stream);
+/* Backward of pp_nerf_fwd: params_grad is ACCUMULATED into (zero it first); g_center[R,3] and g_ray[R,3] are overwritten
+ * (g_ray holds the point and view-direction paths; the compositing path is pp_nerf_composite_bwd's g_ray). */
+int pp_nerf_bwd(const float* params, const float* ray, const float* depth, const int32_t* count, int32_t n_rays,
+                int32_t n_samples, const float* acts, const float* rgb_samples,
+                const float* g_rgb_samples, const float* g_density_samples, float* scratch, float* params_grad,
+                float* g_center, float* g_ray, void* stream);
+/* composite (:290-343): rgb[R,3] (+ 1 - opacity when white_bg), depth[R], opacity[R], weights[R,S], all_cumulated[R]
+ * (= T at the second-to-last sample), rgb_var[R], depth_var[R] (the two variances are forward-only outputs). */
+int pp_nerf_composite_fwd(const float* rgb_samples, const float* density_samples, const float* depth, const float* ray,
+                          int32_t n_rays, int32_t n_samples, int32_t white_bg, float* rgb, float* depth_out, float* opacity,
+                          float* weights, float* all_cumulated, float* rgb_var, float* depth_var, void* stream);
+int pp_nerf_composite_bwd(const float* rgb_samples, const float* density_samples, const float* depth, const float* ray,
+                          const float* weights, int32_t n_rays, int32_t n_samples, int32_t white_bg, const float* g_rgb,
+                          const float* g_depth, const float* g_opacity, const float* g_weights, float* g_rgb_samples,
+                          float* g_density_samples, float* g_ray, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

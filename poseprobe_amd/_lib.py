@@ -37,6 +37,8 @@ def parse_header(path=HEADER):
                 ct = ctypes.c_void_p
             elif 'uint8_t' in a and '*' not in a:
                 ct = ctypes.c_uint8
+            elif 'int64_t' in a:
+                ct = ctypes.c_int64
             elif 'int32_t' in a or a.startswith('int '):
                 ct = ctypes.c_int32
             elif 'float' in a:

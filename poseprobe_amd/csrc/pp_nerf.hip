@@ -1,0 +1,571 @@
+// Scene branch (lib/bg_nerf): the 8 x 256 NeRF MLP with BARF positional encoding and exp-cumsum compositing, forward and
+// backward, exact fp32 on the CDNA4 matrix cores.
+//
+//   reference: lib/bg_nerf/source/models/frequency_nerf.py
+//     :42-69    FrequencyEmbedder          (sin / cos of 2^l * pi * x, layout [coordinate][sin|cos][band])
+//     :152-170  compute_raw_density        (63 -> 256 x 8, skip connection at layer 4, row 0 of the last layer = density)
+//     :189-227  forward                    (softplus density, unit view direction encoding, 283 -> 128 -> 3, sigmoid)
+//     :239-266  positional_encoding        (coarse-to-fine band weights)
+//     :290-343  composite                  (alpha = 1 - exp(-sigma * dist), T = exp(-exclusive cumsum), weights = T * alpha)
+//
+// A 256-wide fp32 layer carries 64 FLOP per byte of activation traffic - twice the machine ridge - so unlike the 128-wide
+// object-branch MLPs this network is bound by the matrix pipe even when it runs layer by layer: every layer is one launch
+// of the persistent 128 x 128-tile NT GEMM of pp_gemm.h (two column blocks over the same row tiles, which therefore meet in
+// L2), all activations stay resident in HBM for the backward pass (9.3 KB per sample, 3.7 GB at 3072 rays x 128 samples),
+// and the data- and weight-gradient GEMMs of the backward pass reuse the same kernels.  The thin ends of the network
+// (encoding, density head, 128 -> 3 colour head, compositing, encoding backward) are bandwidth-bound streaming kernels.
+#include "pp_common.h"
+#include "pp_gemm.h"
+
+#define NERF_L3D 10
+#define NERF_LV 4
+#define NERF_PI 3.14159274101257324f      // float32(pi): the reference builds its frequencies as 2^l * float32(pi)
+
+
+// ------------------------------------------------------------------------------------------------ parameter layout
+// W0[256][64] b0 | W1..W3[256][256] b | W4[256][320] b | W5,W6[256][256] b | wd[256] W7[256][256] | bd b7[256] pad |
+// R0[128][288] br0[128] | R1[3][128] br1[3] pad
+static const int NERF_IN_LD[8] = {64, 256, 256, 256, 320, 256, 256, 256};
+static const int NERF_OUT_LD[8] = {256, 256, 256, 320, 256, 256, 256, 288};
+struct NerfLayout {
+  int64_t w[8], b[8], wd, bd, r0, br0, r1, br1, total;
+};
+static NerfLayout nerf_layout() {
+  NerfLayout L;
+  int64_t o = 0;
+  for (int l = 0; l < 7; ++l) { L.w[l] = o; o += 256 * NERF_IN_LD[l]; L.b[l] = o; o += 256; }
+  // the reference's last feature layer is one [257][256] matrix whose row 0 is the density: wd sits right in front of the
+  // feature rows and bd in front of their biases, so that layer is ONE contiguous tensor for checkpoints / optimisers
+  L.wd = o; o += 256; L.w[7] = o; o += 256 * 256;
+  L.bd = o; o += 1; L.b[7] = o; o += 256; o += 63;
+  L.r0 = o; o += 128 * 288; L.br0 = o; o += 128;
+  L.r1 = o; o += 3 * 128; L.br1 = o; o += 64;
+  L.total = o;
+  return L;
+}
+
+extern "C" int pp_nerf_layout(int64_t* offsets) {
+  PP_REQUIRE(offsets, "null pointer");
+  NerfLayout L = nerf_layout();
+  for (int l = 0; l < 8; ++l) { offsets[2 * l] = L.w[l]; offsets[2 * l + 1] = L.b[l]; }
+  offsets[16] = L.wd; offsets[17] = L.bd; offsets[18] = L.r0; offsets[19] = L.br0; offsets[20] = L.r1; offsets[21] = L.br1;
+  offsets[22] = L.total;
+  return PP_OK;
+}
+
+// activations kept for the backward pass; rows = samples
+struct NerfActs { float* enc; float* a[8]; float* h; float* raw; };
+static NerfActs nerf_acts(float* base, int64_t M) {
+  NerfActs A;
+  float* p = base;
+  A.enc = p; p += M * 64;
+  for (int l = 0; l < 8; ++l) { A.a[l] = p; p += M * NERF_OUT_LD[l]; }
+  A.h = p; p += M * 128;
+  A.raw = p; p += M;
+  return A;
+}
+static int64_t nerf_acts_floats(int64_t M) { return M * (64 + 256 * 6 + 320 + 288 + 128 + 1); }
+static const int64_t NERF_WT_FLOATS = 5 * 65536 + 320 * 256 + 256 * 288 + 64 * 256 + 288 * 128;
+static int64_t nerf_scratch_floats(int64_t M, int64_t R) { return M * (320 * 2 + 64 * 2) + R * (128 + 32) + NERF_WT_FLOATS; }
+
+extern "C" int pp_nerf_workspace(int64_t n_samples, int64_t n_rays, int64_t* acts_floats, int64_t* scratch_floats) {
+  PP_REQUIRE(acts_floats && scratch_floats && n_samples > 0 && n_rays > 0, "bad arguments");
+  *acts_floats = nerf_acts_floats(n_samples);
+  *scratch_floats = nerf_scratch_floats(n_samples, n_rays);
+  return PP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ encoding
+// One wavefront per sample: lane j produces element j of the 64-wide (63 used) encoded point and the 32-wide (27 used)
+// encoded unit view direction; both are written where the consuming layers read them (layer 0 input, the skip columns of
+// layer 4's input, the view columns of the colour head's input), 256-byte coalesced rows.
+__device__ __forceinline__ float nerf_enc_elem(int j, int L, const float* __restrict__ x, const float* __restrict__ w) {
+  if (j < 3) return x[j];
+  const int q = j - 3;
+  if (q >= 6 * L) return 0.f;
+  const int c = q / (2 * L), r = q - c * 2 * L, s = r / L, l = r - s * L;
+  const float ph = x[c] * (NERF_PI * (float)(1 << l));
+  return (s == 0 ? sinf(ph) : cosf(ph)) * w[l];
+}
+
+__global__ __launch_bounds__(256) void k_nerf_encode(const float* __restrict__ center, const float* __restrict__ ray,
+                                                     const float* __restrict__ depth, const float* __restrict__ bands, int M, int S,
+                                                     float* __restrict__ enc, float* __restrict__ a3, float* __restrict__ a7) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int j = threadIdx.x & 63;
+  if (m >= M) return;
+  const int r = m / S;
+  const float t = depth[m];
+  const float d[3] = {ray[r * 3], ray[r * 3 + 1], ray[r * 3 + 2]};
+  float x[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) x[c] = center[r * 3 + c] + d[c] * t;
+  const float e = nerf_enc_elem(j, NERF_L3D, x, bands);
+  enc[(size_t)m * 64 + j] = e;
+  a3[(size_t)m * 320 + 256 + j] = e;
+  if (j < 32) {
+    const float n = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+    const float u[3] = {d[0] / n, d[1] / n, d[2] / n};
+    a7[(size_t)m * 288 + 256 + j] = nerf_enc_elem(j, NERF_LV, u, bands + NERF_L3D);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ thin heads
+__device__ __forceinline__ float nerf_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float nerf_dsoftplus(float x) { return x > 20.f ? 1.f : pp_sigmoid(x); }
+
+// density head: raw = a6 . wd + bd ; one wavefront per sample (float4 per lane)
+__global__ __launch_bounds__(256) void k_nerf_density_fwd(const float* __restrict__ a6, const float* __restrict__ wd,
+                                                          const float* __restrict__ bd, int M, float* __restrict__ raw,
+                                                          float* __restrict__ density) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int j = threadIdx.x & 63;
+  if (m >= M) return;
+  const float4 x = *reinterpret_cast<const float4*>(a6 + (size_t)m * 256 + j * 4);
+  const float4 w = *reinterpret_cast<const float4*>(wd + j * 4);
+  float s = pp_wave_sum(x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w);
+  if (j == 0) { s += bd[0]; raw[m] = s; density[m] = nerf_softplus(s); }
+}
+
+// colour head: rgb = sigmoid(h . R1^T + br1) ; 16 lanes per sample
+__global__ __launch_bounds__(256) void k_nerf_rgb_fwd(const float* __restrict__ R1, const float* __restrict__ br1,
+                                                      const float* __restrict__ h, int M, float* __restrict__ rgb) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = t >> 4, sub = t & 15;
+  const bool live = m < M;
+  float4 xa = make_float4(0, 0, 0, 0), xb = xa;
+  if (live) {
+    const float4* xp = reinterpret_cast<const float4*>(h + (size_t)m * 128 + sub * 8);
+    xa = xp[0]; xb = xp[1];
+  }
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    const float4* wp = reinterpret_cast<const float4*>(R1 + o * 128 + sub * 8);
+    const float4 wa = wp[0], wb = wp[1];
+    float s = xa.x * wa.x + xa.y * wa.y + xa.z * wa.z + xa.w * wa.w + xb.x * wb.x + xb.y * wb.y + xb.z * wb.z + xb.w * wb.w;
+    s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+    if (live && sub == 0) rgb[(size_t)m * 3 + o] = pp_sigmoid(s + br1[o]);
+  }
+}
+
+// colour head backward: dH[m][j] = [h > 0] * sum_o gl_o R1[o][j], R1bar, br1bar ; 64 samples per work-group
+#define NERF_STRIP 256
+__global__ __launch_bounds__(256) void k_nerf_rgb_bwd(const float* __restrict__ R1, const float* __restrict__ h,
+                                                      const float* __restrict__ rgb, const float* __restrict__ g_rgb, int M,
+                                                      float* __restrict__ dH, float* __restrict__ R1bar,
+                                                      float* __restrict__ br1bar) {
+  __shared__ float red[3 * 128 + 4];
+  const int m0 = blockIdx.x * NERF_STRIP;
+  if (m0 >= M) return;
+  const int half = threadIdx.x >> 7, j = threadIdx.x & 127;
+  const float w[3] = {R1[j], R1[128 + j], R1[256 + j]};
+  float wacc[3] = {0, 0, 0}, bacc = 0.f;
+  const int mend = min(m0 + NERF_STRIP, M);
+  for (int m = m0 + half; m < mend; m += 2) {
+    float gl[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) { const float r = rgb[(size_t)m * 3 + o]; gl[o] = g_rgb[(size_t)m * 3 + o] * r * (1.f - r); }
+    const float x = h[(size_t)m * 128 + j];
+    wacc[0] += gl[0] * x; wacc[1] += gl[1] * x; wacc[2] += gl[2] * x;
+    const float hb = gl[0] * w[0] + gl[1] * w[1] + gl[2] * w[2];
+    dH[(size_t)m * 128 + j] = (x > 0.f) ? hb : 0.f;
+    if (j < 3) bacc += gl[j];
+  }
+  if (half == 1) { for (int o = 0; o < 3; ++o) red[o * 128 + j] = wacc[o]; }
+  if (half == 1 && j < 3) red[384 + j] = bacc;
+  __syncthreads();
+  if (half == 0) { for (int o = 0; o < 3; ++o) atomicAdd(&R1bar[o * 128 + j], wacc[o] + red[o * 128 + j]); }
+  if (half == 0 && j < 3) atomicAdd(&br1bar[j], bacc + red[384 + j]);
+}
+
+// density head backward: column 256 of the last feature layer's output gradient carries d raw; wd / bd gradients.
+__global__ __launch_bounds__(256) void k_nerf_density_bwd(const float* __restrict__ a6, const float* __restrict__ raw,
+                                                          const float* __restrict__ g_density, int M,
+                                                          float* __restrict__ dY7, float* __restrict__ wdbar,
+                                                          float* __restrict__ bdbar) {
+  const int m0 = blockIdx.x * NERF_STRIP;
+  if (m0 >= M) return;
+  const int k = threadIdx.x;
+  float acc = 0.f, bacc = 0.f;
+  const int mend = min(m0 + NERF_STRIP, M);
+  for (int m = m0; m < mend; ++m) {
+    const float g = g_density[m] * nerf_dsoftplus(raw[m]);
+    acc += g * a6[(size_t)m * 256 + k];
+    if (k < 32) dY7[(size_t)m * 288 + 256 + k] = (k == 0) ? g : 0.f;
+    bacc += g;
+  }
+  atomicAdd(&wdbar[k], acc);
+  if (k == 0) atomicAdd(&bdbar[0], bacc);
+}
+
+// dst[c * ldd + r] = src[r * lds + c]
+__global__ __launch_bounds__(256) void k_nerf_transpose(const float* __restrict__ src, int lds, int rows, int cols,
+                                                        float* __restrict__ dst, int ldd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int c = i / rows, r = i - c * rows;
+  dst[(size_t)c * ldd + r] = src[(size_t)r * lds + c];
+}
+
+// column 256 of the transposed last feature layer = density row wd ; columns 257..287 stay zero
+__global__ void k_nerf_wd_column(const float* __restrict__ wd, float* __restrict__ w7t) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= 256) return;
+  w7t[(size_t)k * 288 + 256] = wd[k];
+  for (int c = 257; c < 288; ++c) w7t[(size_t)k * 288 + c] = 0.f;
+}
+
+// dHsum[r][j] = sum over the S samples of ray r of dH[m][j]
+__global__ __launch_bounds__(128) void k_nerf_ray_sum(const float* __restrict__ dH, int R, int S, float* __restrict__ out) {
+  const int r = blockIdx.x, j = threadIdx.x;
+  if (r >= R) return;
+  float acc = 0.f;
+  const float* p = dH + (size_t)r * S * 128 + j;
+  for (int s = 0; s < S; ++s) acc += p[(size_t)s * 128];
+  out[(size_t)r * 128 + j] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ compositing
+// One wavefront per ray; lane i owns samples i, i + 64, ... ; exclusive prefix sums of sigma * dist by wave scan.
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float n = __shfl_up(v, o, 64);
+    if (lane >= o) v += n;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_nerf_composite_fwd(const float* __restrict__ rgb_s, const float* __restrict__ density,
+                                                            const float* __restrict__ depth, const float* __restrict__ ray,
+                                                            int R, int S, int white_bg, float* __restrict__ rgb,
+                                                            float* __restrict__ depth_out, float* __restrict__ opacity,
+                                                            float* __restrict__ weights, float* __restrict__ all_cum,
+                                                            float* __restrict__ rgb_var, float* __restrict__ depth_var) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float len = sqrtf(ray[r * 3] * ray[r * 3] + ray[r * 3 + 1] * ray[r * 3 + 1] + ray[r * 3 + 2] * ray[r * 3 + 2]);
+  const size_t base = (size_t)r * S;
+  float carry = 0.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_o = 0.f, t_pen = 1.f;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    float sd = 0.f, t = 0.f;
+    if (s < S) {
+      t = depth[base + s];
+      const float intv = (s + 1 < S) ? depth[base + s + 1] - t : 1e10f;
+      sd = density[base + s] * (intv * len);
+    }
+    const float incl = wave_incl_scan(sd, lane);
+    const float prev = __shfl_up(incl, 1, 64);                    // exclusive prefix without "incl - sd": the last interval
+    const float T = expf(-(carry + (lane > 0 ? prev : 0.f)));     // is 1e10 long and would cancel the prefix away
+    if (s < S) {
+      const float w = T * (1.f - expf(-sd));
+      weights[base + s] = w;
+      acc_r += w * rgb_s[(base + s) * 3]; acc_g += w * rgb_s[(base + s) * 3 + 1]; acc_b += w * rgb_s[(base + s) * 3 + 2];
+      acc_d += w * t; acc_o += w;
+      if (s == S - 2) t_pen = T;
+    }
+    carry += __shfl(incl, 63, 64);
+  }
+  acc_r = pp_wave_sum(acc_r); acc_g = pp_wave_sum(acc_g); acc_b = pp_wave_sum(acc_b);
+  acc_d = pp_wave_sum(acc_d); acc_o = pp_wave_sum(acc_o);
+  // second pass for the two variance outputs (forward only, they feed logging in the reference)
+  float vr = 0.f, vd = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float w = weights[base + s];
+    const float dt = depth[base + s] - acc_d;
+    vd += w * dt * dt;
+    vr += w * ((rgb_s[(base + s) * 3] - acc_r) + (rgb_s[(base + s) * 3 + 1] - acc_g) + (rgb_s[(base + s) * 3 + 2] - acc_b));
+  }
+  vr = pp_wave_sum(vr); vd = pp_wave_sum(vd);
+  const int pen_lane = (S - 2) & 63;
+  const float tp = __shfl(t_pen, pen_lane, 64);
+  if (lane == 0) {
+    const float bgc = white_bg ? (1.f - acc_o) : 0.f;
+    rgb[r * 3] = acc_r + bgc; rgb[r * 3 + 1] = acc_g + bgc; rgb[r * 3 + 2] = acc_b + bgc;
+    depth_out[r] = acc_d; opacity[r] = acc_o; all_cum[r] = (S >= 2) ? tp : 1.f;
+    rgb_var[r] = vr; depth_var[r] = vd;
+  }
+}
+
+// g_sd[j] = gw[j] * T[j+1] - sum_{i > j} gw[i] * w[i]  with  gw[i] = g_rgb . rgb_s[i] + g_depth * t[i] + g_op + g_w[i]
+__global__ __launch_bounds__(256) void k_nerf_composite_bwd(const float* __restrict__ rgb_s, const float* __restrict__ density,
+                                                            const float* __restrict__ depth, const float* __restrict__ ray,
+                                                            const float* __restrict__ weights, int R, int S, int white_bg,
+                                                            const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
+                                                            const float* __restrict__ g_op, const float* __restrict__ g_w,
+                                                            float* __restrict__ g_rgb_s, float* __restrict__ g_density,
+                                                            float* __restrict__ g_ray) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float d0 = ray[r * 3], d1 = ray[r * 3 + 1], d2 = ray[r * 3 + 2];
+  const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+  const size_t base = (size_t)r * S;
+  const float gr = g_rgb[r * 3], gg = g_rgb[r * 3 + 1], gb = g_rgb[r * 3 + 2];
+  const float gd = g_depth[r];
+  const float go = g_op[r] - (white_bg ? (gr + gg + gb) : 0.f);
+  // forward prefix (for T) chunk by chunk, kept per chunk in registers would need S/64 slots: recompute T from the
+  // exclusive prefix in a first sweep, the suffix sum in a second (reverse) sweep.
+  float total_after = 0.f;      // sum_{i > chunk} gw[i] * w[i]
+  float g_len = 0.f;
+  const int nchunk = (S + 63) >> 6;
+  // prefix of sd at chunk starts
+  float carry_arr[8];
+  {
+    float carry = 0.f;
+    for (int c = 0; c < nchunk && c < 8; ++c) {
+      carry_arr[c] = carry;
+      const int s = c * 64 + lane;
+      float sd = 0.f;
+      if (s < S) {
+        const float t = depth[base + s];
+        const float intv = (s + 1 < S) ? depth[base + s + 1] - t : 1e10f;
+        sd = density[base + s] * (intv * len);
+      }
+      carry += pp_wave_sum(sd);
+    }
+  }
+  for (int c = nchunk - 1; c >= 0; --c) {
+    const int s = c * 64 + lane;
+    float sd = 0.f, t = 0.f, intv = 0.f, dens = 0.f, w = 0.f, gw = 0.f;
+    if (s < S) {
+      t = depth[base + s];
+      intv = (s + 1 < S) ? depth[base + s + 1] - t : 1e10f;
+      dens = density[base + s];
+      sd = dens * (intv * len);
+      w = weights[base + s];
+      const float cr = rgb_s[(base + s) * 3], cg = rgb_s[(base + s) * 3 + 1], cb = rgb_s[(base + s) * 3 + 2];
+      gw = gr * cr + gg * cg + gb * cb + gd * t + go + (g_w ? g_w[base + s] : 0.f);
+      g_rgb_s[(base + s) * 3] = gr * w; g_rgb_s[(base + s) * 3 + 1] = gg * w; g_rgb_s[(base + s) * 3 + 2] = gb * w;
+    }
+    const float incl = wave_incl_scan(sd, lane);
+    const float Tnext = expf(-(carry_arr[c] + incl));             // T[s + 1]
+    const float gww = gw * w;
+    const float incl_g = wave_incl_scan(gww, lane);
+    // read the chunk total at the LAST VALID lane: there "chunk_sum - incl_g" is exactly zero, which the final sample needs
+    // (its interval is 1e10 long - any rounding residue of two differently associated sums would be multiplied by it)
+    const float chunk_sum = __shfl(incl_g, min(63, S - 1 - c * 64), 64);
+    const float after = total_after + (chunk_sum - incl_g);       // sum over i > s
+    if (s < S) {
+      const float gsd = gw * Tnext - after;
+      g_density[base + s] = gsd * (intv * len);
+      g_len += gsd * dens * intv;
+    }
+    total_after += chunk_sum;
+  }
+  g_len = pp_wave_sum(g_len);
+  if (lane == 0) {
+    const float inv = (len > 0.f) ? g_len / len : 0.f;
+    g_ray[r * 3] = inv * d0; g_ray[r * 3 + 1] = inv * d1; g_ray[r * 3 + 2] = inv * d2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ encoding backward
+// One work-group (4 wavefronts) per ray; a wavefront walks every 4th sample, lane j owns element j of the encoding
+// gradient (layer 0's plus the skip layer's).  d/dx of w sin(f x) is f * (w cos(f x)) - the partner element of the stored
+// encoding - so no trigonometry is re-evaluated.  The tail adds the view-direction path (through the normalisation) and
+// writes d center = sum_s d pts, d ray = sum_s depth * d pts + view term.
+__global__ __launch_bounds__(256) void k_nerf_encode_bwd(const float* __restrict__ enc, const float* __restrict__ dEnc0,
+                                                         const float* __restrict__ dEncS, const float* __restrict__ dView,
+                                                         const float* __restrict__ a7, const float* __restrict__ ray,
+                                                         const float* __restrict__ depth, int R, int S,
+                                                         float* __restrict__ g_center, float* __restrict__ g_ray) {
+  __shared__ float red[4][6];
+  const int r = blockIdx.x;
+  const int wid = threadIdx.x >> 6, j = threadIdx.x & 63;
+  // static role of lane j
+  int c = -1, sgn = 0, partner = j;
+  float f = 0.f;
+  if (j < 3) { c = j; }
+  else if (j < 3 + 6 * NERF_L3D) {
+    const int q = j - 3;
+    c = q / (2 * NERF_L3D);
+    const int rr = q - c * 2 * NERF_L3D, s = rr / NERF_L3D, l = rr - s * NERF_L3D;
+    f = NERF_PI * (float)(1 << l);
+    sgn = (s == 0) ? 1 : -1;
+    partner = (s == 0) ? j + NERF_L3D : j - NERF_L3D;
+  }
+  float gc[3] = {0.f, 0.f, 0.f}, gr[3] = {0.f, 0.f, 0.f};
+  for (int s = wid; s < S; s += 4) {
+    const size_t m = (size_t)r * S + s;
+    const float g = dEnc0[m * 64 + j] + dEncS[m * 64 + j];
+    const float e = enc[m * 64 + j];
+    const float ep = __shfl(e, partner, 64);
+    const float contrib = (j < 3) ? g : (float)sgn * f * ep * g;
+    const float p0 = pp_wave_sum(c == 0 ? contrib : 0.f);
+    const float p1 = pp_wave_sum(c == 1 ? contrib : 0.f);
+    const float p2 = pp_wave_sum(c == 2 ? contrib : 0.f);
+    const float t = depth[m];
+    gc[0] += p0; gc[1] += p1; gc[2] += p2;
+    gr[0] += t * p0; gr[1] += t * p1; gr[2] += t * p2;
+  }
+  if (j == 0) { for (int i = 0; i < 3; ++i) { red[wid][i] = gc[i]; red[wid][3 + i] = gr[i]; } }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float o[6];
+    for (int i = 0; i < 6; ++i) o[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    // view-direction path: venc = (u, w sin(f u), w cos(f u)), u = ray / |ray|
+    const float d[3] = {ray[r * 3], ray[r * 3 + 1], ray[r * 3 + 2]};
+    const float n = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+    const float* ve = a7 + (size_t)r * S * 288 + 256;          // encoded view direction of the ray's first sample
+    const float* gv = dView + (size_t)r * 32;
+    float gu[3], u[3], dot = 0.f;
+    for (int cc = 0; cc < 3; ++cc) {
+      u[cc] = d[cc] / n;
+      float acc = gv[cc];
+      for (int l = 0; l < NERF_LV; ++l) {
+        const float fl = NERF_PI * (float)(1 << l);
+        const int js = 3 + cc * 2 * NERF_LV + l, jc = js + NERF_LV;
+        acc += fl * (ve[jc] * gv[js] - ve[js] * gv[jc]);
+      }
+      gu[cc] = acc;
+      dot += u[cc] * acc;
+    }
+    for (int cc = 0; cc < 3; ++cc) {
+      g_center[r * 3 + cc] = o[cc];
+      g_ray[r * 3 + cc] = o[3 + cc] + (gu[cc] - u[cc] * dot) / n;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static const int NERF_BM = 128;
+static const int NERF_GEMM_WGS = 384;     // persistent work-groups per column block (3 resident per CU at BM = 128)
+static const int NERF_TN_WGS = 224;       // row splits of a weight-gradient block (each ends in 64 KB of atomics)
+
+template <int EPI>
+static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, int K, int Nout, const float* bias,
+                      const float* mask, int ldm, float* C, int ldc, const int32_t* count, int rows) {
+  const int tiles = pp_div_up(rows, NERF_BM);
+  dim3 g(tiles < NERF_GEMM_WGS ? tiles : NERF_GEMM_WGS, pp_div_up(Nout, 128)), b(256);
+  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI, 1, NERF_BM>), g, b, 0, st, A, lda, W, ldw, K, Nout, bias, mask, ldm, C, ldc,
+                     count, 1, rows);
+}
+
+static void nerf_gemm_tn(hipStream_t st, const float* Y, int ldy, int N, const float* X, int ldx, int Kx, float* Wbar,
+                         float* bbar, const int32_t* count, int rows) {
+  dim3 g(NERF_TN_WGS, (N / 128) * pp_div_up(Kx, 128)), b(256);
+  hipLaunchKernelGGL((k_gemm_tn<1>), g, b, 0, st, Y, ldy, X, ldx, Kx, Wbar, ldx, bbar, count, 1, rows);
+}
+
+extern "C" int pp_nerf_fwd(const float* params, const float* center, const float* ray, const float* depth,
+                           const float* bands, const int32_t* count, int32_t n_rays, int32_t n_samples, float* acts,
+                           float* rgb_samples, float* density_samples, void* stream) {
+  PP_REQUIRE(params && center && ray && depth && bands && count && acts && rgb_samples && density_samples, "null pointer");
+  PP_REQUIRE(n_rays > 0 && n_samples > 0 && (int64_t)n_rays * n_samples < (1LL << 30), "bad sizes");
+  hipStream_t st = pp_stream(stream);
+  const int M = n_rays * n_samples;
+  const NerfLayout L = nerf_layout();
+  NerfActs A = nerf_acts(acts, M);
+  hipLaunchKernelGGL(k_nerf_encode, dim3(pp_div_up(M, 4)), dim3(256), 0, st, center, ray, depth, bands, M,
+                     n_samples, A.enc, A.a[3], A.a[7]);
+  const float* in = A.enc;
+  for (int l = 0; l < 8; ++l) {
+    nerf_gemm<EPI_RELU>(st, in, NERF_IN_LD[l], params + L.w[l], NERF_IN_LD[l], NERF_IN_LD[l], 256, params + L.b[l], nullptr, 0,
+                        A.a[l], NERF_OUT_LD[l], count, M);
+    in = A.a[l];
+  }
+  hipLaunchKernelGGL(k_nerf_density_fwd, dim3(pp_div_up(M, 4)), dim3(256), 0, st, A.a[6], params + L.wd, params + L.bd, M,
+                     A.raw, density_samples);
+  nerf_gemm<EPI_RELU>(st, A.a[7], 288, params + L.r0, 288, 288, 128, params + L.br0, nullptr, 0, A.h, 128, count, M);
+  hipLaunchKernelGGL(k_nerf_rgb_fwd, dim3(pp_div_up(M * 16, 256)), dim3(256), 0, st, params + L.r1, params + L.br1, A.h, M,
+                     rgb_samples);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* depth, const int32_t* count,
+                           int32_t n_rays, int32_t n_samples, const float* acts, const float* rgb_samples, const float* g_rgb_samples,
+                           const float* g_density_samples, float* scratch, float* params_grad, float* g_center, float* g_ray,
+                           void* stream) {
+  PP_REQUIRE(params && ray && depth && count && acts && rgb_samples && g_rgb_samples && g_density_samples && scratch &&
+                 params_grad && g_center && g_ray, "null pointer");
+  PP_REQUIRE(n_rays > 0 && n_samples > 0 && (int64_t)n_rays * n_samples < (1LL << 30), "bad sizes");
+  hipStream_t st = pp_stream(stream);
+  const int R = n_rays, S = n_samples, M = R * S;
+  const NerfLayout L = nerf_layout();
+  NerfActs A = nerf_acts(const_cast<float*>(acts), M);
+  float* P = scratch;
+  float* Q = P + (size_t)M * 320;
+  float* dEnc0 = Q + (size_t)M * 320;
+  float* dEncS = dEnc0 + (size_t)M * 64;
+  float* dHsum = dEncS + (size_t)M * 64;
+  float* dView = dHsum + (size_t)R * 128;
+  float* wt = dView + (size_t)R * 32;
+  float* WT[8];
+  {
+    float* p = wt;
+    for (int l = 0; l < 8; ++l) { WT[l] = p; p += (l == 7) ? 256 * 288 : 256 * NERF_IN_LD[l]; }
+  }
+  float* R0T = WT[7] + 256 * 288;                  // [288][128]
+  dim3 b(256);
+  // transposed weights for the data-gradient GEMMs (2 MB, L2 resident)
+  for (int l = 0; l < 7; ++l)
+    hipLaunchKernelGGL(k_nerf_transpose, dim3(pp_div_up(256 * NERF_IN_LD[l], 256)), b, 0, st, params + L.w[l], NERF_IN_LD[l],
+                       256, NERF_IN_LD[l], WT[l], 256);
+  hipLaunchKernelGGL(k_nerf_transpose, dim3(256), b, 0, st, params + L.w[7], 256, 256, 256, WT[7], 288);
+  hipLaunchKernelGGL(k_nerf_wd_column, dim3(1), b, 0, st, params + L.wd, WT[7]);
+  hipLaunchKernelGGL(k_nerf_transpose, dim3(pp_div_up(128 * 288, 256)), b, 0, st, params + L.r0, 288, 128, 288, R0T, 128);
+
+  // colour head
+  float* dH = Q;                                   // [M][128]
+  hipLaunchKernelGGL(k_nerf_rgb_bwd, dim3(pp_div_up(M, NERF_STRIP)), b, 0, st, params + L.r1, A.h, rgb_samples, g_rgb_samples,
+                     M, dH, params_grad + L.r1, params_grad + L.br1);
+  nerf_gemm_tn(st, dH, 128, 128, A.a[7], 288, 288, params_grad + L.r0, params_grad + L.br0, count, M);
+  hipLaunchKernelGGL(k_nerf_ray_sum, dim3(R), dim3(128), 0, st, dH, R, S, dHsum);
+  nerf_gemm<EPI_PLAIN>(st, dHsum, 128, R0T + 256 * 128, 128, 128, 32, nullptr, nullptr, 0, dView, 32, count, R);
+  // last feature layer: columns 0..255 through the colour head, column 256 from the density
+  nerf_gemm<EPI_MASK>(st, dH, 128, R0T, 128, 128, 256, nullptr, A.a[7], 288, P, 288, count, M);
+  hipLaunchKernelGGL(k_nerf_density_bwd, dim3(pp_div_up(M, NERF_STRIP)), b, 0, st, A.a[6], A.raw, g_density_samples, M, P,
+                     params_grad + L.wd, params_grad + L.bd);
+  nerf_gemm_tn(st, P, 288, 256, A.a[6], 256, 256, params_grad + L.w[7], params_grad + L.b[7], count, M);
+  nerf_gemm<EPI_MASK>(st, P, 288, WT[7], 288, 288, 256, nullptr, A.a[6], 256, Q, 256, count, M);
+  float* cur = Q;
+  float* nxt = P;
+  for (int l = 6; l >= 1; --l) {                   // cur = d(pre-activation of layer l), [M][256]
+    const float* x = A.a[l - 1];
+    const int ldx = NERF_OUT_LD[l - 1];            // 320 for layer 4's input (features + skip columns)
+    nerf_gemm_tn(st, cur, 256, 256, x, ldx, NERF_IN_LD[l], params_grad + L.w[l], params_grad + L.b[l], count, M);
+    nerf_gemm<EPI_MASK>(st, cur, 256, WT[l], 256, 256, 256, nullptr, x, ldx, nxt, 256, count, M);
+    if (l == 4)                                    // skip columns: gradient of the encoding, no activation in between
+      nerf_gemm<EPI_PLAIN>(st, cur, 256, WT[4] + 256 * 256, 256, 256, 64, nullptr, nullptr, 0, dEncS, 64, count, M);
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  nerf_gemm_tn(st, cur, 256, 256, A.enc, 64, 64, params_grad + L.w[0], params_grad + L.b[0], count, M);
+  nerf_gemm<EPI_PLAIN>(st, cur, 256, WT[0], 256, 256, 64, nullptr, nullptr, 0, dEnc0, 64, count, M);
+  hipLaunchKernelGGL(k_nerf_encode_bwd, dim3(R), b, 0, st, A.enc, dEnc0, dEncS, dView, A.a[7], ray, depth, R, S, g_center,
+                     g_ray);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_nerf_composite_fwd(const float* rgb_samples, const float* density_samples, const float* depth,
+                                     const float* ray, int32_t n_rays, int32_t n_samples, int32_t white_bg, float* rgb,
+                                     float* depth_out, float* opacity, float* weights, float* all_cumulated, float* rgb_var,
+                                     float* depth_var, void* stream) {
+  PP_REQUIRE(rgb_samples && density_samples && depth && ray && rgb && depth_out && opacity && weights && all_cumulated &&
+                 rgb_var && depth_var, "null pointer");
+  PP_REQUIRE(n_rays > 0 && n_samples > 0 && n_samples <= 512, "bad sizes");
+  hipLaunchKernelGGL(k_nerf_composite_fwd, dim3(pp_div_up(n_rays, 4)), dim3(256), 0, pp_stream(stream), rgb_samples,
+                     density_samples, depth, ray, n_rays, n_samples, white_bg, rgb, depth_out, opacity, weights, all_cumulated,
+                     rgb_var, depth_var);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_nerf_composite_bwd(const float* rgb_samples, const float* density_samples, const float* depth,
+                                     const float* ray, const float* weights, int32_t n_rays, int32_t n_samples,
+                                     int32_t white_bg, const float* g_rgb, const float* g_depth, const float* g_opacity,
+                                     const float* g_weights, float* g_rgb_samples, float* g_density_samples, float* g_ray,
+                                     void* stream) {
+  PP_REQUIRE(rgb_samples && density_samples && depth && ray && weights && g_rgb && g_depth && g_opacity && g_rgb_samples &&
+                 g_density_samples && g_ray, "null pointer");
+  PP_REQUIRE(n_rays > 0 && n_samples > 0 && n_samples <= 512, "bad sizes");
+  hipLaunchKernelGGL(k_nerf_composite_bwd, dim3(pp_div_up(n_rays, 4)), dim3(256), 0, pp_stream(stream), rgb_samples,
+                     density_samples, depth, ray, weights, n_rays, n_samples, white_bg, g_rgb, g_depth, g_opacity, g_weights,
+                     g_rgb_samples, g_density_samples, g_ray);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}

@@ -304,3 +304,42 @@ def mlp_bwd(params, feat, in_ld, n_gemm, acts, out, out_grad, count, capacity, s
 def march_dvgo_fwd(alpha, rgb, step_w, ray_start, n_rays, weights, T, alphainv_last, i_end, rgb_acc, cum_weights, depth_acc):
     _lib.call('pp_march_dvgo_fwd', _f(alpha), _f(rgb), _f(step_w), _i(ray_start), n_rays, _f(weights), _f(T),
               _f(alphainv_last), _i(i_end), _f(rgb_acc), _f(cum_weights), _f(depth_acc), _stream())
+
+
+# ------------------------------------------------------------------------------------------- scene branch (NeRF)
+def nerf_layout():
+    """Offsets (floats) of {W0,b0,...,W7,b7,wd,bd,R0,br0,R1,br1} in the packed parameter block and its total size."""
+    off = (ctypes.c_int64 * 23)()
+    _lib.call('pp_nerf_layout', off)
+    return list(off)
+
+
+def nerf_workspace(n_samples, n_rays):
+    a, s = ctypes.c_int64(), ctypes.c_int64()
+    _lib.call('pp_nerf_workspace', ctypes.c_int64(n_samples), ctypes.c_int64(n_rays), ctypes.byref(a), ctypes.byref(s))
+    return a.value, s.value
+
+
+def nerf_fwd(params, center, ray, depth, bands, count, n_rays, n_samples, acts, rgb_samples, density_samples):
+    _lib.call('pp_nerf_fwd', _f(params), _f(center), _f(ray), _f(depth), _f(bands), _i(count), int(n_rays), int(n_samples),
+              _f(acts), _f(rgb_samples), _f(density_samples), _stream())
+
+
+def nerf_bwd(params, ray, depth, count, n_rays, n_samples, acts, rgb_samples, g_rgb_samples, g_density_samples, scratch,
+             params_grad, g_center, g_ray):
+    _lib.call('pp_nerf_bwd', _f(params), _f(ray), _f(depth), _i(count), int(n_rays), int(n_samples), _f(acts), _f(rgb_samples),
+              _f(g_rgb_samples), _f(g_density_samples), _f(scratch), _f(params_grad), _f(g_center), _f(g_ray), _stream())
+
+
+def nerf_composite_fwd(rgb_samples, density_samples, depth, ray, n_rays, n_samples, white_bg, rgb, depth_out, opacity, weights,
+                       all_cumulated, rgb_var, depth_var):
+    _lib.call('pp_nerf_composite_fwd', _f(rgb_samples), _f(density_samples), _f(depth), _f(ray), int(n_rays), int(n_samples),
+              int(bool(white_bg)), _f(rgb), _f(depth_out), _f(opacity), _f(weights), _f(all_cumulated), _f(rgb_var),
+              _f(depth_var), _stream())
+
+
+def nerf_composite_bwd(rgb_samples, density_samples, depth, ray, weights, n_rays, n_samples, white_bg, g_rgb, g_depth, g_opacity,
+                       g_weights, g_rgb_samples, g_density_samples, g_ray):
+    _lib.call('pp_nerf_composite_bwd', _f(rgb_samples), _f(density_samples), _f(depth), _f(ray), _f(weights), int(n_rays),
+              int(n_samples), int(bool(white_bg)), _f(g_rgb), _f(g_depth), _f(g_opacity), _f(g_weights), _f(g_rgb_samples),
+              _f(g_density_samples), _f(g_ray), _stream())

@@ -60,3 +60,20 @@ def assert_close(a, b, rtol=1e-5, atol=1e-6, name='', scaled=0.0):
     bad = err > tol
     assert not bad.any(), (f'{name}: {bad.sum()}/{a.size} mismatches, max abs err {err.max():.3e}, '
                            f'max |ref| {np.abs(b).max():.3e}')
+
+
+def assert_mostly_close(a, b, rtol, scaled, name='', outlier_frac=0.03, outlier_scaled=3e-2):
+    """For gradients of ReLU networks compared across two fp32 implementations: a pre-activation that lies within rounding
+    distance of zero flips its mask in one of them and changes that sample's contribution discretely (a handful of the ~1e7
+    activations of a test do).  Rows (first dimension) are therefore allowed to miss the tight tolerance in at most
+    `outlier_frac` of the cases, and every element has to meet the loose bound `outlier_scaled` * max|b|."""
+    a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, dtype=np.float64)
+    assert a.shape == b.shape, f'{name}: shape {a.shape} vs {b.shape}'
+    err = np.abs(a - b)
+    mx = np.abs(b).max()
+    loose = err > outlier_scaled * mx + rtol * np.abs(b)
+    assert not loose.any(), f'{name}: {loose.sum()}/{a.size} beyond the loose bound, max abs err {err.max():.3e}, max |ref| {mx:.3e}'
+    bad = (err > rtol * np.abs(b) + scaled * mx).reshape(a.shape[0], -1).any(axis=1)
+    assert bad.mean() <= outlier_frac, (f'{name}: {bad.sum()}/{bad.size} rows miss the tight tolerance '
+                                        f'(max abs err {err.max():.3e}, max |ref| {mx:.3e})')

@@ -1,0 +1,51 @@
+"""Pins the scene-branch oracle (oracle/scene_nerf.py) against the fixture produced by executing the reference's
+frequency_nerf.NeRF (oracle/make_golden.py: gen_scene).  CPU only."""
+import numpy as np
+import torch
+
+from oracle import scene_nerf as SN
+from tests.helpers import assert_close, load
+
+
+def scene_inputs(d, dtype=torch.float32):
+    P = {k[6:]: torch.tensor(v, dtype=dtype).requires_grad_(True) for k, v in d.items() if k.startswith('param.')}
+    B, N, S = int(d['B']), int(d['N']), int(d['S'])
+    center = torch.tensor(d['center'], dtype=dtype).reshape(B * N, 3).requires_grad_(True)
+    ray = torch.tensor(d['ray'], dtype=dtype).reshape(B * N, 3).requires_grad_(True)
+    depth = torch.tensor(d['depth_samples'], dtype=dtype).reshape(B * N, S)
+    return P, center, ray, depth
+
+
+def linear_functional(d, out):
+    total = 0.
+    for k in ('rgb', 'depth', 'opacity', 'weights', 'rgb_samples', 'density_samples'):
+        c = torch.tensor(d['lf_coef_' + k]).reshape(out[k].shape).to(out[k].dtype)
+        total = total + (c * out[k]).sum()
+    return total
+
+
+def test_scene_oracle_matches_reference_outputs_and_gradients():
+    d = load('scene_b2.npz')
+    P, center, ray, depth = scene_inputs(d)
+    out = SN.render(P, center, ray, depth, float(d['progress']), tuple(d['barf_c2f']))
+    for k in ('rgb_samples', 'density_samples', 'rgb', 'rgb_var', 'depth', 'depth_var', 'opacity', 'weights', 'all_cumulated'):
+        assert_close(out[k].reshape(-1), d['out.' + k].reshape(-1), rtol=2e-5, atol=2e-6, name=k)
+    total = linear_functional(d, out)
+    assert_close(total, d['lf_value'], rtol=1e-5, atol=1e-4, name='lf_value')
+    total.backward()
+    assert_close(center.grad.reshape(-1), d['lf_g_center'].reshape(-1), rtol=1e-4, scaled=1e-5, name='g_center')
+    assert_close(ray.grad.reshape(-1), d['lf_g_ray'].reshape(-1), rtol=1e-4, scaled=1e-5, name='g_ray')
+    for k, p in P.items():
+        assert_close(p.grad, d['lf_g.' + k], rtol=1e-4, scaled=1e-5, name='g.' + k)
+
+
+def test_scene_oracle_photometric_loss():
+    d = load('scene_b2.npz')
+    rgb = torch.tensor(d['out.rgb'])
+    assert_close(SN.photometric_loss(rgb, torch.tensor(d['loss_image'])), d['loss_render'], rtol=1e-6, name='loss_render')
+
+
+def test_band_weights_window():
+    w = SN.band_weights(0.565, (0.4, 0.7), 10)
+    assert np.all(w[:5].numpy() == 1.0) and np.all(w[6:].numpy() == 0.0) and 0.0 < float(w[5]) < 1.0
+    assert torch.equal(SN.band_weights(0.1, None, 4), torch.ones(4))
