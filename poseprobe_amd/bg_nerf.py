@@ -61,13 +61,16 @@ def sample_depth(opt, batch_size, num_rays, n_samples, depth_range, mode=None, d
     return {'metric': depth, 'inverse': 1 / (depth + 1e-8)}[opt.nerf.depth.param]
 
 
-def sample_depth_from_pdf(weights, n_samples_coarse, n_samples_fine, depth_range, det, generator=None):
-    """Inverse-transform sampling from the coarse weights (renderer.py:702-738); weights [B, R, N] -> [B, R, Nf, 1]."""
+def sample_depth_from_pdf(weights, n_samples_coarse, n_samples_fine, depth_range, det, generator=None, grid=None):
+    """Inverse-transform sampling from the coarse weights (renderer.py:702-738); weights [B, R, N] -> [B, R, Nf, 1].
+    `grid` [Nf + 1] replays a recorded draw of the (shared across rays) uniform grid."""
     depth_min, depth_max = depth_range
     dev = weights.device
     pdf = weights / (weights.sum(dim=-1, keepdim=True) + 1e-6)
     cdf = torch.cat([torch.zeros_like(pdf[..., :1]), pdf.cumsum(dim=-1)], dim=-1)
-    if det:
+    if grid is not None:
+        grid = grid.to(dev)
+    elif det:
         grid = torch.linspace(0, 1, n_samples_fine + 1, device=dev)
     else:
         grid = torch.rand(n_samples_fine + 1, generator=generator).to(dev)
@@ -289,6 +292,83 @@ class NeRF(torch.nn.Module):
         pred_dict.update(rgb=rgb.view(B, N, 3), rgb_var=rv.view(B, N, 1), depth=d.view(B, N, 1), depth_var=dv.view(B, N, 1),
                          opacity=op.view(B, N, 1), weights=w.view(B, N, S, 1), all_cumulated=cum.view(B, N))
         return pred_dict
+
+
+def _cam2world(X, pose_w2c):
+    """camera -> world for points X [B, N, 3] under world-to-camera poses [B, 3, 4] (utils/camera.py:321-338)."""
+    Rinv = pose_w2c[..., :3].transpose(-1, -2)
+    c2w = torch.cat([Rinv, -Rinv @ pose_w2c[..., 3:]], dim=-1)
+    return torch.cat([X, torch.ones_like(X[..., :1])], dim=-1) @ c2w.transpose(-1, -2)
+
+
+def get_center_and_ray_at_pixels(pose_w2c, pixels, intr):
+    """Camera centres and un-normalised ray directions of given pixels (utils/camera.py:384-416): pixels [N, 2] (shared by
+    all images) or [B, N, 2]; differentiable w.r.t. the poses through a handful of per-ray torch ops."""
+    B = len(pose_w2c)
+    xy = pixels.unsqueeze(0).repeat(B, 1, 1) if pixels.dim() == 2 else pixels
+    grid = torch.cat([xy, torch.ones_like(xy[..., :1])], dim=-1) @ intr.inverse().transpose(-1, -2)
+    center = _cam2world(torch.zeros_like(grid), pose_w2c)
+    return center, _cam2world(grid, pose_w2c) - center
+
+
+def get_center_and_ray(pose_w2c, H, W, intr):
+    """All H * W pixel centres (x + 0.5, y + 0.5), row-major (utils/camera.py:347-381)."""
+    dev = pose_w2c.device
+    Y, X = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=dev) + 0.5,
+                          torch.arange(W, dtype=torch.float32, device=dev) + 0.5, indexing='ij')
+    return get_center_and_ray_at_pixels(pose_w2c, torch.stack([X, Y], dim=-1).view(-1, 2), intr)
+
+
+class SceneRenderer:
+    """The render path of the reference's `Graph` (renderer.py:532-627): rays from poses, stratified coarse samples, coarse
+    NeRF + compositing and - once `iter` has passed `ratio_start_fine_sampling_at_x * max_iter` - the fine NeRF on the union of
+    the coarse samples and inverse-transform samples of the coarse weights.  Returns the same keys (`*_fine` for the second
+    pass).  `rand` (optional) replays recorded uniform draws: [coarse [B, N, S, 1], fine grid [Nf + 1]]."""
+
+    def __init__(self, opt, device='cuda'):
+        self.opt, self.device = opt, torch.device(device)
+        self.nerf = NeRF(opt, device=device)
+        self.nerf_fine = NeRF(opt, is_fine_network=True, device=device) if opt.nerf.fine_sampling else None
+
+    def render(self, opt, pose, H, W, intr, pixels=None, ray_idx=None, depth_range=None, iter=None, mode=None, rand=None):
+        B = len(pose)
+        if pixels is not None:
+            center, ray = get_center_and_ray_at_pixels(pose, pixels, intr)
+        else:
+            center, ray = get_center_and_ray(pose, H, W, intr)
+            if ray_idx is not None:
+                if ray_idx.dim() == 2 and ray_idx.shape[0] == B:
+                    bi = torch.arange(B, device=ray_idx.device)[:, None]
+                    center, ray = center[bi, ray_idx.long()], ray[bi, ray_idx.long()]
+                else:
+                    center, ray = center[:, ray_idx], ray[:, ray_idx]
+        if opt.camera.ndc:
+            raise NotImplementedError('bg_nerf: NDC rays are not used by any PoseProbe configuration')
+        N, S = ray.shape[1], opt.nerf.sample_intvs
+        pred = Options(origins=center, viewdirs=ray)
+        if rand is not None:
+            jitter = rand[0].to(self.device) + torch.arange(S, device=self.device)[None, None, :, None].float()
+            depth = jitter / S * (depth_range[1] - depth_range[0]) + depth_range[0]
+            depth = {'metric': depth, 'inverse': 1 / (depth + 1e-8)}[opt.nerf.depth.param]
+        else:
+            depth = sample_depth(opt, B, N, S, depth_range, mode=mode, device=self.device)
+        coarse = self.nerf.forward_samples(opt, center, ray, depth, mode=mode)
+        coarse['t'] = depth
+        pred.update(self.nerf.composite(opt, ray, coarse, depth))
+        start = getattr(opt.nerf, 'ratio_start_fine_sampling_at_x', None)
+        skip_fine = start is not None and iter is not None and iter < opt.max_iter * start
+        if opt.nerf.fine_sampling and not skip_fine:
+            with torch.no_grad():
+                det = mode not in ('train', 'test-optim') or not opt.nerf.sample_stratified
+                grid = rand[1].to(self.device) if (rand is not None and not det) else None
+                fine_t = sample_depth_from_pdf(pred['weights'][..., 0].detach(), S, opt.nerf.sample_intvs_fine, depth_range,
+                                               det=det, grid=grid)
+            depth = torch.cat([depth, fine_t], dim=2).sort(dim=2).values
+            fine = self.nerf_fine.forward_samples(opt, center, ray, depth, mode=mode)
+            fine['t'] = depth
+            fine = self.nerf_fine.composite(opt, ray, fine, depth)
+            pred.update({k + '_fine': v for k, v in fine.items()})
+        return pred
 
 
 def photometric_loss(rgb, image, huber=True):

@@ -217,3 +217,34 @@ def test_scene_unsupported_architecture_is_refused():
     opt.arch.layers_feat = [None] + [128] * 8
     with pytest.raises(NotImplementedError):
         bg_nerf.NeRF(opt, device='cuda')
+
+
+@pytest.mark.parametrize('label,it', [('early', 100), ('late', 500)])
+def test_scene_renderer_matches_reference_render(label, it):
+    """SceneRenderer.render == the reference's Graph.render (executed by oracle/make_golden.py: gen_scene_render) with the
+    recorded uniform draws replayed: coarse pass only before ratio_start_fine_sampling_at_x, coarse + fine after it.  The
+    fine depth samples come from the coarse weights through a searchsorted, so they are compared like everything else."""
+    from poseprobe_amd import bg_nerf
+    d = load('scene_render.npz')
+    opt = bg_nerf.default_options(sample_intvs=int(d['n_coarse']))
+    opt.nerf.sample_intvs_fine, opt.nerf.fine_sampling = int(d['n_fine']), True
+    opt.nerf.ratio_start_fine_sampling_at_x, opt.max_iter = 0.3, 1000
+    sr = bg_nerf.SceneRenderer(opt, device='cuda')
+    for ni, net in enumerate((sr.nerf, sr.nerf_fine)):
+        sd = {k[len(f'param{ni}.'):]: torch.tensor(v.astype(np.float32)) for k, v in d.items() if k.startswith(f'param{ni}.')}
+        sd['progress'] = torch.tensor(float(d['progress']))
+        net.load_state_dict(sd)
+    rand = [torch.tensor(d[f'{label}.rand{i}']) for i in range(2 if label == 'late' else 1)]
+    ret = sr.render(opt, torch.tensor(d['pose']).cuda(), 32, 32, torch.tensor(d['intr']).cuda(),
+                    pixels=torch.tensor(d['pixels']).cuda(), depth_range=[float(x) for x in d['depth_range']], iter=it,
+                    mode='train', rand=rand)
+    keys = [k[len(label) + 1:] for k in d if k.startswith(label + '.') and 'rand' not in k]
+    assert ('rgb_fine' in keys) == (label == 'late') and ('rgb_fine' in ret) == (label == 'late')
+    for k in keys:
+        assert tuple(ret[k].shape) == tuple(d[f'{label}.{k}'].shape), k
+        if k.endswith('_fine') and k != 't_fine':
+            # fine sample positions inherit ~1e-6 differences of the coarse weights; the active 128*pi band turns them into
+            # ~1e-4 differences of the network outputs at those samples
+            assert_close(ret[k], d[f'{label}.{k}'], rtol=2e-3, atol=5e-4, name=k)
+        else:
+            assert_close(ret[k], d[f'{label}.{k}'], rtol=5e-5, atol=5e-6, name=k)

@@ -49,3 +49,23 @@ def test_band_weights_window():
     w = SN.band_weights(0.565, (0.4, 0.7), 10)
     assert np.all(w[:5].numpy() == 1.0) and np.all(w[6:].numpy() == 0.0) and 0.0 < float(w[5]) < 1.0
     assert torch.equal(SN.band_weights(0.1, None, 4), torch.ones(4))
+
+
+def test_scene_host_helpers_match_reference_render():
+    """Host-side pieces of SceneRenderer (per-ray torch algebra, no kernels): rays at pixels (utils/camera.py:384-416) and
+    the coarse-to-fine inverse-transform sampler (renderer.py:702-738) against the recorded reference render."""
+    from poseprobe_amd import bg_nerf
+    d = load('scene_render.npz')
+    center, ray = bg_nerf.get_center_and_ray_at_pixels(torch.tensor(d['pose']), torch.tensor(d['pixels']), torch.tensor(d['intr']))
+    assert_close(center, d['late.origins'], rtol=1e-6, atol=1e-6, name='origins')
+    assert_close(ray, d['late.viewdirs'], rtol=1e-6, atol=1e-6, name='viewdirs')
+    lo, hi = (float(x) for x in d['depth_range'])
+    fine = bg_nerf.sample_depth_from_pdf(torch.tensor(d['late.weights'])[..., 0], int(d['n_coarse']), int(d['n_fine']), (lo, hi),
+                                         det=False, grid=torch.tensor(d['late.rand1']))
+    t = torch.cat([torch.tensor(d['late.t']), fine], dim=2).sort(dim=2).values
+    assert_close(t, d['late.t_fine'], rtol=1e-6, atol=1e-6, name='t_fine')
+    opt = bg_nerf.default_options(sample_intvs=int(d['n_coarse']))
+    dep = bg_nerf.sample_depth(opt, 2, 20, int(d['n_coarse']), (lo, hi), mode='val', device='cpu')
+    step = (hi - lo) / int(d['n_coarse'])
+    assert_close(dep[0, 0, :, 0], lo + step * (np.arange(int(d['n_coarse'])) + 0.5), rtol=1e-6, name='midpoints')
+    assert bool(((torch.tensor(d['late.t'])[..., 0] >= lo) & (torch.tensor(d['late.t'])[..., 0] <= hi)).all())

@@ -1,7 +1,7 @@
 """Times one scene-branch optimisation step (SceneEngine.step) at the reference's training size and prints per-kernel-free
 wall numbers; run under rocprofv3 for the kernel table."""
 import sys, time, json, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from poseprobe_amd import bg_nerf
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 128
