@@ -1,0 +1,94 @@
+"""Dual-branch step (poseprobe_amd.joint): both branches share the poses; se3 receives the sum of their gradients
+(loss = 0.1 * L_obj + L_bg, lib/recon_scene.py:645-649)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close, load
+from tests.test_hip_step import build_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene_batch(d, V, N, S, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    H, W = int(d['H']), int(d['W'])
+    pixels = (torch.rand(N, 2, generator=g) * torch.tensor([W - 1., H - 1.])).cuda()
+    image = torch.rand(V, N, 3, generator=g).cuda()
+    rand = torch.rand(V, N, S, 1, generator=g).cuda()
+    return pixels, image, rand
+
+
+def test_joint_step_pose_gradient_is_the_sum_of_both_branches():
+    from poseprobe_amd import bg_nerf, camera
+    from poseprobe_amd.joint import DualBranchEngine
+    d = load('forward_g24_s10.npz')
+    ray_idx = torch.tensor(d['ray_idx'], dtype=torch.int32, device='cuda')
+    jitter = torch.tensor(d['jitter'], device='cuda')
+    gs = int(d['global_step'])
+    opt = bg_nerf.default_options(sample_intvs=24)
+    torch.manual_seed(5)
+    net = bg_nerf.NeRF(opt, device='cuda')
+    net.progress.data.fill_(0.6)
+    V, N, S = 3, 40, 24
+    pixels, image, rand = _scene_batch(d, V, N, S)
+
+    ref, _ = build_engine(d)                       # object branch alone
+    ref.zero_grads()
+    ref.render_and_grads(ray_idx, jitter, gs)
+    g_obj = ref.se3_grad.clone()
+    flat_obj, k0_obj = ref.flat.grad.clone(), ref.k0_grad.clone()
+
+    eng, _ = build_engine(d)
+    joint = DualBranchEngine(eng, net, depth_range=(0.5, 3.0))
+    eng.zero_grads()
+    _, loss_bg = joint.forward_backward(ray_idx, jitter, gs, pixels, image, depth_rand=rand)
+    assert_close(eng.flat.grad, flat_obj, rtol=1e-4, scaled=1e-5, name='object MLP grads untouched by the scene branch')
+    assert_close(eng.k0_grad.sum(), k0_obj.sum(), rtol=1e-4, name='k0 grad')
+
+    # the scene branch's share by autograd: se3 -> (HIP pose chain) -> c2w -> rays -> NeRF autograd nodes -> loss
+    se3 = eng.se3.detach().clone().requires_grad_(True)
+    _, c2w = camera.current_pose_c2w(se3, eng.w2c_init, fix_first=True)
+    fx, fy, cx, cy = (eng.intr[:, i][:, None] for i in range(4))
+    x, y = pixels[None, :, 0], pixels[None, :, 1]
+    dir_cam = torch.stack([(x - cx) / fx, (y - cy) / fy, torch.ones(V, N, device='cuda')], -1)
+    ray = dir_cam @ c2w[:, :, :3].transpose(-1, -2)
+    center = c2w[:, None, :, 3].expand_as(ray)
+    depth = (rand + torch.arange(S, device='cuda')[None, None, :, None]) / S * 2.5 + 0.5
+    net2 = bg_nerf.NeRF(opt, device='cuda')
+    net2.load_state_dict(net.state_dict())
+    pred = net2.composite(opt, ray, net2.forward_samples(opt, center, ray, depth, mode='train'), depth)
+    loss = bg_nerf.photometric_loss(pred['rgb'], image)
+    loss.backward()
+    assert_close(loss_bg, loss, rtol=1e-5, name='scene loss')
+    assert_close(eng.se3_grad - g_obj, se3.grad, rtol=1e-3, scaled=2e-3, name='scene share of the pose gradient')
+    assert float((eng.se3_grad - g_obj).abs().max()) > 0
+    # the scene engine's parameter gradients equal the autograd node's
+    views = net2._views(joint.scene.grad)
+    for (name, p), gv in zip([(n, p) for n, p in net2.named_parameters() if n != 'progress'], views):
+        assert_close(gv, p.grad, rtol=1e-4, scaled=2e-5, name='scene g.' + name)
+
+
+def test_joint_train_steps_run_and_reduce_both_losses():
+    from poseprobe_amd import bg_nerf
+    from poseprobe_amd.joint import DualBranchEngine
+    d = load('forward_g24_s10.npz')
+    eng, _ = build_engine(d)
+    opt = bg_nerf.default_options(sample_intvs=24)
+    torch.manual_seed(6)
+    net = bg_nerf.NeRF(opt, device='cuda')
+    net.progress.data.fill_(0.3)
+    joint = DualBranchEngine(eng, net, lr_scene=5e-4)
+    ray_idx = torch.tensor(d['ray_idx'], dtype=torch.int32, device='cuda')
+    jitter = torch.tensor(d['jitter'], device='cuda')
+    pixels, image, rand = _scene_batch(d, 3, 64, 24)
+    image = image * 0 + torch.tensor([0.2, 0.5, 0.7]).cuda()          # a learnable target: constant colour
+    eng.zero_grads()
+    se3_before = eng.se3.clone()
+    losses = []
+    for it in range(30):
+        _, loss_bg = joint.train_step(ray_idx, jitter, int(d['global_step']) + it, pixels, image, depth_rand=rand)
+        losses.append(float(loss_bg))
+    assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0], losses
+    assert float((eng.se3 - se3_before).abs().max()) > 0           # poses moved (views other than the fixed first one)
+    assert float((eng.se3 - se3_before)[0].abs().max()) == 0.0
