@@ -83,6 +83,40 @@ def cpu_baseline(G, H, W, V, n_rand, views, budget_s=20.0):
                       f'median {t:.3f} s/step'}
 
 
+def dual_branch_leg(eng, idx_all, jit_all, gs, N, V, H, W, object_ms, dev, steps=20, warmup=3):
+    """Informative second measurement (never `value`): the same object-branch step plus the scene branch of the reference's
+    joint loop (lib/recon_scene.py:639-649): rand_rays // V pixels per view x 128 stratified samples through the 8 x 256
+    NeRF, 2 * huber loss, backward, Adam, poses shared through the object engine's pose Jacobian."""
+    from poseprobe_amd import bg_nerf
+    from poseprobe_amd.joint import DualBranchEngine
+    opt = bg_nerf.default_options(sample_intvs=128)
+    torch.manual_seed(0)
+    net = bg_nerf.NeRF(opt, device=dev)
+    net.progress.data.fill_(0.5)
+    joint = DualBranchEngine(eng, net, lr_scene=1e-3, depth_range=(0.5, 3.0))
+    n_pix, S = opt.nerf.rand_rays // V, 128
+    g = torch.Generator().manual_seed(1)
+    px = [(torch.rand(n_pix, 2, generator=g) * torch.tensor([W - 1., H - 1.])).to(dev) for _ in range(steps + warmup)]
+    img = torch.rand(V, n_pix, 3, generator=g).to(dev)
+    n_avail = idx_all.shape[0]
+    for s in range(warmup):
+        joint.train_step(idx_all[s % n_avail], jit_all[s % n_avail], gs + s, px[s], img)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(warmup, warmup + steps):
+        joint.train_step(idx_all[s % n_avail], jit_all[s % n_avail], gs + s, px[s], img)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    M = V * n_pix * S
+    flop = 3 * 2 * M * (64 * 256 + 6 * 256 * 256 + 320 * 256 + 256 + 288 * 128 + 128 * 3)     # fwd + data grad + weight grad
+    scene_ms = ms - object_ms
+    return {'workload': f'object-branch step + scene branch: {V} x {n_pix} rays x {S} stratified samples, 8x256 NeRF (BARF PE), '
+                        f'2*huber loss, backward, Adam; shared poses, loss = 0.1 L_obj + L_bg',
+            'ms_per_step': ms, 'rays_per_s': (N + V * n_pix) / (ms * 1e-3), 'object_rays': N, 'scene_rays': V * n_pix,
+            'scene_samples': M, 'scene_ms': scene_ms, 'scene_mfma_tflops': flop / (scene_ms * 1e-3) / 1e12,
+            'scene_mfma_frac_of_fp32_peak': flop / (scene_ms * 1e-3) / 1e12 / 157.3, 'n_gpus': 1}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -94,6 +128,7 @@ def main():
     ap.add_argument('--views', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
+    ap.add_argument('--no-dual', action='store_true', help='skip the informative dual-branch (object + scene) leg')
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON record).  Libraries that print to fd 1 (RCCL prints a version banner when
@@ -213,6 +248,10 @@ def main():
     mlp_ms = float(np.sum([a.elapsed_time(b) for a, b in mlp_ev])) / max(extra, 1) if mlp_ev else float('nan')
     mlp_tflops = flop_per_sample * M / (mlp_ms * 1e-3) / 1e12
 
+    dual = None
+    if world == 1 and not args.no_dual:
+        dual = dual_branch_leg(eng, idx_all, jit_all, gs, N, V, H, W, dt / args.steps * 1e3, dev)
+
     if rank == 0:
         out = {
             'metric': 'rays_per_sec_train_step', 'value': N * world * args.steps / dt, 'unit': 'rays/s',
@@ -230,6 +269,7 @@ def main():
                               'achieved': mlp_tflops, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': mlp_tflops / 157.3,
                               'ms_per_step': mlp_ms, 'flop_per_sample': flop_per_sample},
         }
+        out['dual_branch'] = dual
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(G, H, W, V, N, views, args.cpu_budget)
         else:
