@@ -10,15 +10,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum { MODE_NT = 0 };
 enum { EPI_RELU = 0, EPI_MASK = 1, EPI_PLAIN = 2 };
 
-template <int EPI, int COLS, bool FULL, int TM>
-__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][2], int r0, int R, int Nout, int wr, int wc, int l31,
+template <int EPI, int COLS, bool FULL, int TM, int TNW = 2>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TNW], int r0, int R, int Nout, int wr, int wc, int l31,
                                               int lh, const float* __restrict__ bias,
                                               const float* __restrict__ Xmask, int ldm, float* __restrict__ C, int ldc) {
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int col = wc * 64 + u * 32 + l31;
+    for (int u = 0; u < TNW; ++u) {
+      const int col = wc * (32 * TNW) + u * 32 + l31;
       if (!FULL && col >= Nout) continue;
       const float bcol = (EPI == EPI_RELU && bias) ? bias[col] : 0.f;
       const int rbase = r0 + wr * (32 * TM) + t * 32 + 4 * lh;
@@ -54,21 +54,25 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][2], int r0, int 
 }
 
 // C[r][n] = epi( sum_k A[r][k] * B(n,k) ),  NT: B(n,k) = W[n*ldw + k]   NN: B(n,k) = W[k*ldw + n]
-template <int MODE, int EPI, int COLS, int BM>
-__global__ __launch_bounds__(256) void k_gemm128(const float* __restrict__ A, int lda, const float* __restrict__ W_,
+// Register budget: the 128-column tile is left to the compiler (it takes 190-280 registers, 1-2 wavefronts per SIMD; capping
+// it at 168 for three work-groups per CU measured 10 % slower); the 256-column tile is capped at 256.
+template <int MODE, int EPI, int COLS, int BM, int BN = 128>
+__global__ __launch_bounds__(256, (BN == 256 ? 2 : 1)) void k_gemm128(const float* __restrict__ A, int lda, const float* __restrict__ W_,
                                                  int ldw, int K, int Nout_, const float* __restrict__ bias_,
                                                  const float* __restrict__ Xmask_, int ldm, float* __restrict__ C_,
                                                  int ldc, const int32_t* __restrict__ count, int rmul, int rcap) {
   constexpr int TM = BM / 64;            // 32-row MFMA tiles per wavefront (waves are arranged 2 x 2)
   constexpr int NA = BM / 32;            // float4 of the A tile per thread and K-chunk
+  constexpr int TNW = BN / 64;           // 32-column MFMA tiles per wavefront
+  constexpr int NB = BN / 32;            // float4 of the B tile per thread and K-chunk
   __shared__ float As[BM * LDT];
-  __shared__ float Bs[128 * LDT];
-  const int cb = blockIdx.y * 128;       // column block of the output
+  __shared__ float Bs[BN * LDT];
+  const int cb = blockIdx.y * BN;        // column block of the output
   const float* __restrict__ W = W_ + (size_t)cb * ldw;
   const float* __restrict__ bias = bias_ ? bias_ + cb : nullptr;
   const float* __restrict__ Xmask = Xmask_ ? Xmask_ + cb : nullptr;
   float* __restrict__ C = C_ + cb;
-  const int Nout = min(128, Nout_ - cb);
+  const int Nout = min(BN, Nout_ - cb);
   const int R = min(count[0] * rmul, rcap);
   const int ntiles = (R + BM - 1) / BM;
   int tile = blockIdx.x;
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void k_gemm128(const float* __restrict__ A, in
   // Persistent work-group: tiles blockIdx.x, +gridDim.x, ...  Software pipeline: the global loads of the NEXT K-chunk -
   // or of the next tile's first chunk - are issued before the MFMA block of the current chunk (register staging), so
   // HBM/L2 latency hides behind the matrix pipe and the chip-wide load bursts of lock-stepped work-groups disappear.
-  float4 ra[NA], rw[4];
+  float4 ra[NA], rw[NB];
   auto load_chunk = [&](int r0, int k0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) void k_gemm128(const float* __restrict__ A, in
       if (gr < R) ra[i] = *reinterpret_cast<const float4*>(A + (size_t)gr * lda + k0 + c4 * 4);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NB; ++i) {
       int e = tid + i * 256;
       int row = e >> 3, c4 = e & 7;
       rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -101,11 +105,11 @@ __global__ __launch_bounds__(256) void k_gemm128(const float* __restrict__ A, in
   load_chunk(tile * BM, 0);
   for (; tile < ntiles; tile += gridDim.x) {
     const int r0 = tile * BM;
-    f32x16 acc[TM][2];
+    f32x16 acc[TM][TNW];
 #pragma unroll
     for (int t = 0; t < TM; ++t)
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < TNW; ++u)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
     for (int k0 = 0; k0 < K; k0 += 32) {
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void k_gemm128(const float* __restrict__ A, in
         *reinterpret_cast<float4*>(As + (e >> 3) * LDT + (e & 7) * 4) = ra[i];
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NB; ++i) {
         int e = tid + i * 256;
         *reinterpret_cast<float4*>(Bs + (e >> 3) * LDT + (e & 7) * 4) = rw[i];
       }
@@ -130,27 +134,29 @@ __global__ __launch_bounds__(256) void k_gemm128(const float* __restrict__ A, in
 #pragma unroll
         for (int t = 0; t < TM; ++t)
           a[t] = *reinterpret_cast<const float4*>(As + (wr * (32 * TM) + t * 32 + l31) * LDT + kb + 4 * lh);
-        const float4 b0 = *reinterpret_cast<const float4*>(Bs + (wc * 64 + l31) * LDT + kb + 4 * lh);
-        const float4 b1 = *reinterpret_cast<const float4*>(Bs + (wc * 64 + 32 + l31) * LDT + kb + 4 * lh);
+        float4 b[TNW];
+#pragma unroll
+        for (int u = 0; u < TNW; ++u)
+          b[u] = *reinterpret_cast<const float4*>(Bs + (wc * (32 * TNW) + u * 32 + l31) * LDT + kb + 4 * lh);
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b0.x, acc[t][0], 0, 0, 0);
-          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b1.x, acc[t][1], 0, 0, 0);
-          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b0.y, acc[t][0], 0, 0, 0);
-          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b1.y, acc[t][1], 0, 0, 0);
-          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b0.z, acc[t][0], 0, 0, 0);
-          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b1.z, acc[t][1], 0, 0, 0);
-          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b0.w, acc[t][0], 0, 0, 0);
-          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b1.w, acc[t][1], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < TNW; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < TNW; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < TNW; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < TNW; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
         }
       }
       __syncthreads();
     }
     // epilogue.  Full tiles (all but the last one) take a branch-free instantiation.
-    if ((r0 + BM <= R) && (Nout == 128))
-      gemm_epilogue<EPI, COLS, true, TM>(acc, r0, R, Nout, wr, wc, l31, lh, bias, Xmask, ldm, C, ldc);
+    if ((r0 + BM <= R) && (Nout == BN))
+      gemm_epilogue<EPI, COLS, true, TM, TNW>(acc, r0, R, Nout, wr, wc, l31, lh, bias, Xmask, ldm, C, ldc);
     else
-      gemm_epilogue<EPI, COLS, false, TM>(acc, r0, R, Nout, wr, wc, l31, lh, bias, Xmask, ldm, C, ldc);
+      gemm_epilogue<EPI, COLS, false, TM, TNW>(acc, r0, R, Nout, wr, wc, l31, lh, bias, Xmask, ldm, C, ldc);
   }
 }
 

@@ -16,6 +16,7 @@
 // (encoding, density head, 128 -> 3 colour head, compositing, encoding backward) are bandwidth-bound streaming kernels.
 #include "pp_common.h"
 #include "pp_gemm.h"
+#include <stdlib.h>
 
 #define NERF_L3D 10
 #define NERF_LV 4
@@ -433,13 +434,30 @@ __global__ __launch_bounds__(256) void k_nerf_encode_bwd(const float* __restrict
 // ------------------------------------------------------------------------------------------------ host side
 static const int NERF_BM = 128;
 static const int NERF_GEMM_WGS = 384;     // persistent work-groups per column block (3 resident per CU at BM = 128)
+static const int NERF_GEMM_WGS_WIDE = 512;   // 128 x 256 tiles: 2 resident per CU (55 KB LDS, ~220 registers)
 static const int NERF_TN_WGS = 224;       // row splits of a weight-gradient block (each ends in 64 KB of atomics)
+
+// PP_NERF_BN=256 selects 128 x 256 tiles (activation tile read once, half the barriers per MFMA).  Measured SLOWER on
+// MI355X (3072 x 128 samples: 15.8 vs 13.8 ms per step): 128 accumulators + operand staging do not fit 256 registers without
+// spills inside the K loop, and at 512 registers one work-group per CU cannot hide its own barriers.  Kept for A/B runs.
+static int nerf_wide_tiles() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PP_NERF_BN"); v = (e && atoi(e) == 256) ? 1 : 0; }
+  return v;
+}
 
 template <int EPI>
 static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, int K, int Nout, const float* bias,
                       const float* mask, int ldm, float* C, int ldc, const int32_t* count, int rows) {
   const int tiles = pp_div_up(rows, NERF_BM);
-  dim3 g(tiles < NERF_GEMM_WGS ? tiles : NERF_GEMM_WGS, pp_div_up(Nout, 128)), b(256);
+  dim3 b(256);
+  if (Nout == 256 && nerf_wide_tiles()) {    // 128 x 256 tile: the activation tile is read once, half the barriers per MFMA
+    dim3 g(tiles < NERF_GEMM_WGS_WIDE ? tiles : NERF_GEMM_WGS_WIDE, 1);
+    hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI, 1, NERF_BM, 256>), g, b, 0, st, A, lda, W, ldw, K, Nout, bias, mask, ldm, C,
+                       ldc, count, 1, rows);
+    return;
+  }
+  dim3 g(tiles < NERF_GEMM_WGS ? tiles : NERF_GEMM_WGS, pp_div_up(Nout, 128));
   hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI, 1, NERF_BM>), g, b, 0, st, A, lda, W, ldw, K, Nout, bias, mask, ldm, C, ldc,
                      count, 1, rows);
 }
