@@ -433,9 +433,10 @@ __global__ __launch_bounds__(256) void k_nerf_encode_bwd(const float* __restrict
 
 // ------------------------------------------------------------------------------------------------ host side
 static const int NERF_BM = 128;
-static const int NERF_GEMM_WGS = 384;     // persistent work-groups per column block (3 resident per CU at BM = 128)
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && atoi(e) > 0) ? atoi(e) : dflt; }
+static const int NERF_GEMM_WGS = env_int("PP_NERF_GEMM_WGS", 256);     // persistent work-groups per column block (measured: 256 = 512 > 384 > 128)
 static const int NERF_GEMM_WGS_WIDE = 512;   // 128 x 256 tiles: 2 resident per CU (55 KB LDS, ~220 registers)
-static const int NERF_TN_WGS = 224;       // row splits of a weight-gradient block (each ends in 64 KB of atomics)
+static const int NERF_TN_WGS = env_int("PP_NERF_TN_WGS", 256);        // row splits of a weight-gradient block (each ends in 64 KB of atomics)
 
 // PP_NERF_BN=256 selects 128 x 256 tiles (activation tile read once, half the barriers per MFMA).  Measured SLOWER on
 // MI355X (3072 x 128 samples: 15.8 vs 13.8 ms per step): 128 accumulators + operand staging do not fit 256 registers without
@@ -455,6 +456,12 @@ static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, i
     dim3 g(tiles < NERF_GEMM_WGS_WIDE ? tiles : NERF_GEMM_WGS_WIDE, 1);
     hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI, 1, NERF_BM, 256>), g, b, 0, st, A, lda, W, ldw, K, Nout, bias, mask, ldm, C,
                        ldc, count, 1, rows);
+    return;
+  }
+  if (Nout <= 64) {                          // encoding / view-direction gradients: 64-column tile instead of a half-empty one
+    dim3 g(tiles < 2 * NERF_GEMM_WGS ? tiles : 2 * NERF_GEMM_WGS, 1);
+    hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI, 1, NERF_BM, 64>), g, b, 0, st, A, lda, W, ldw, K, Nout, bias, mask, ldm, C, ldc,
+                       count, 1, rows);
     return;
   }
   dim3 g(tiles < NERF_GEMM_WGS ? tiles : NERF_GEMM_WGS, pp_div_up(Nout, 128));

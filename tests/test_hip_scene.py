@@ -119,8 +119,9 @@ def test_scene_matches_oracle_on_seeded_rays(R, S, white):
     # ReLU masks that flip within rounding distance of zero (a handful per pass at these sizes, see helpers) change ONE
     # sample's contribution: a few rays of the ray gradients, and every row of the weight gradients by that sample's share
     # (~1e-3 of the largest entry).  The flip-free reference fixture above pins the same quantities at 1e-4 / 2e-5.
-    assert_mostly_close(c.grad, center.grad, rtol=1e-4, scaled=5e-5, name='g_center', outlier_frac=0.1)
-    assert_mostly_close(r.grad, ray.grad, rtol=1e-4, scaled=5e-5, name='g_ray', outlier_frac=0.1)
+    # (expected flips per pass ~ 6e-7 x activations: ~2 at 96 x 40 samples, ~10 at 37 x 200 - each touches one ray)
+    assert_mostly_close(c.grad, center.grad, rtol=1e-4, scaled=5e-5, name='g_center', outlier_frac=0.35)
+    assert_mostly_close(r.grad, ray.grad, rtol=1e-4, scaled=5e-5, name='g_ray', outlier_frac=0.35)
     for name, p in net.named_parameters():
         if name != 'progress':
             assert_close(p.grad, P[name].grad, rtol=1e-3, scaled=2e-3, name='g.' + name)
