@@ -169,12 +169,13 @@ static __global__ __launch_bounds__(256) void k_transpose(const float* __restric
 }
 
 // Wbar[n][k] += sum_r Y[r][n] * X[r][k]   (n < 128, k < Kx) ;  bbar[n] += sum_{r % COLS == 0} Y[r][n]
-template <int COLS>
+template <int COLS, int CH = 32>
 __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ Y_, int ldy, const float* __restrict__ X_, int ldx,
                                                  int Kx_, float* __restrict__ Wbar_, int ldwb, float* __restrict__ bbar_,
                                                  const int32_t* __restrict__ count, int rmul, int rcap) {
-  __shared__ float Ys[32 * 128];
-  __shared__ float Xs[32 * 128];
+  constexpr int NL = CH / 8;             // float4 per thread, matrix and row chunk (CH rows of 128 floats)
+  __shared__ float Ys[CH * 128];
+  __shared__ float Xs[CH * 128];
   const int nkb = (Kx_ + 127) >> 7;      // gridDim.y = (N / 128) * nkb blocks of 128 x 128 weight gradients
   const int nb = blockIdx.y / nkb, kb = blockIdx.y - nb * nkb;
   const float* __restrict__ Y = Y_ + nb * 128;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ Y_, i
   float* __restrict__ Wbar = Wbar_ + (size_t)nb * 128 * ldwb + kb * 128;
   float* __restrict__ bbar = (bbar_ && kb == 0) ? bbar_ + nb * 128 : nullptr;
   const int R = min(count[0] * rmul, rcap);
-  const int rows_per_wg = ((R + (int)gridDim.x - 1) / (int)gridDim.x + 31) & ~31;   // multiple of 32 (and of COLS)
+  const int rows_per_wg = ((R + (int)gridDim.x - 1) / (int)gridDim.x + CH - 1) / CH * CH;   // multiple of CH (and of COLS)
   const int rb = blockIdx.x * rows_per_wg;
   if (rb >= R) return;
   const int re = min(rb + rows_per_wg, R);
@@ -200,10 +201,10 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ Y_, i
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
   float bsum = 0.f;
   const int kx4 = Kx >> 2;
-  float4 ry[4], rx[4];
+  float4 ry[NL], rx[NL];
   auto load_rows = [&](int r0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
       int e = tid + i * 256;
       int rr = e >> 5, c4 = e & 31;
       int gr = r0 + rr;
@@ -215,20 +216,22 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ Y_, i
       }
     }
   };
+  // bias gradient: every thread sums half of the chunk's rows of one column (both halves of the work-group share the work)
+  const int bcol = tid & 127, bhalf = tid >> 7;
   load_rows(rb);
-  for (int r0 = rb; r0 < re; r0 += 32) {
+  for (int r0 = rb; r0 < re; r0 += CH) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
       int e = tid + i * 256;
       int rr = e >> 5, c4 = e & 31;
       *reinterpret_cast<float4*>(Ys + rr * 128 + c4 * 4) = ry[i];
       *reinterpret_cast<float4*>(Xs + rr * 128 + c4 * 4) = rx[i];
     }
     __syncthreads();
-    if (r0 + 32 < re) load_rows(r0 + 32);
+    if (r0 + CH < re) load_rows(r0 + CH);
     if (active) {
 #pragma unroll 4
-      for (int kk = 0; kk < 32; kk += 2) {
+      for (int kk = 0; kk < CH; kk += 2) {
         const int ridx = kk + lh;
         float a0 = Ys[ridx * 128 + wr * 64 + l31];
         float a1 = Ys[ridx * 128 + wr * 64 + 32 + l31];
@@ -240,9 +243,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ Y_, i
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
       }
     }
-    if (tid < 128) {
+    if (bbar) {
 #pragma unroll
-      for (int rr = 0; rr < 32; rr += COLS) bsum += Ys[rr * 128 + tid];   // r0 is a multiple of 32 -> rr%COLS==0 rows
+      for (int rr = 0; rr < CH / 2; rr += COLS) bsum += Ys[(bhalf * (CH / 2) + rr) * 128 + bcol];   // chunk starts are multiples of COLS
     }
     __syncthreads();
   }
@@ -260,5 +263,5 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ Y_, i
         }
       }
   }
-  if (tid < 128 && bbar) atomicAdd(&bbar[tid], bsum);
+  if (bbar) atomicAdd(&bbar[bcol], bsum);
 }

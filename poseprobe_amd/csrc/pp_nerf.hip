@@ -436,6 +436,7 @@ static const int NERF_BM = 128;
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && atoi(e) > 0) ? atoi(e) : dflt; }
 static const int NERF_GEMM_WGS = env_int("PP_NERF_GEMM_WGS", 256);     // persistent work-groups per column block (measured: 256 = 512 > 384 > 128)
 static const int NERF_GEMM_WGS_WIDE = 512;   // 128 x 256 tiles: 2 resident per CU (55 KB LDS, ~220 registers)
+static const int NERF_TN_CH = env_int("PP_NERF_TN_CH", 64);           // rows per LDS chunk of the weight-gradient GEMM (32 | 64)
 static const int NERF_TN_WGS = env_int("PP_NERF_TN_WGS", 256);        // row splits of a weight-gradient block (each ends in 64 KB of atomics)
 
 // PP_NERF_BN=256 selects 128 x 256 tiles (activation tile read once, half the barriers per MFMA).  Measured SLOWER on
@@ -472,7 +473,10 @@ static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, i
 static void nerf_gemm_tn(hipStream_t st, const float* Y, int ldy, int N, const float* X, int ldx, int Kx, float* Wbar,
                          float* bbar, const int32_t* count, int rows) {
   dim3 g(NERF_TN_WGS, (N / 128) * pp_div_up(Kx, 128)), b(256);
-  hipLaunchKernelGGL((k_gemm_tn<1>), g, b, 0, st, Y, ldy, X, ldx, Kx, Wbar, ldx, bbar, count, 1, rows);
+  if (NERF_TN_CH == 64)
+    hipLaunchKernelGGL((k_gemm_tn<1, 64>), g, b, 0, st, Y, ldy, X, ldx, Kx, Wbar, ldx, bbar, count, 1, rows);
+  else
+    hipLaunchKernelGGL((k_gemm_tn<1>), g, b, 0, st, Y, ldy, X, ldx, Kx, Wbar, ldx, bbar, count, 1, rows);
 }
 
 extern "C" int pp_nerf_fwd(const float* params, const float* center, const float* ray, const float* depth,
