@@ -240,17 +240,19 @@ class NeRF(torch.nn.Module):
     # ------------------------------------------------------------------------------------------------------------
     def band_weights(self):
         """Device tensor [14]: coarse-to-fine weights of the 10 point bands and the 4 view bands (frequency_nerf.py:255-262),
-        computed on the device from `progress` so the schedule never forces a host synchronisation."""
+        computed on the device from `progress` (the trainer updates it with in-place fills on `.data`, which no version
+        counter sees) so the schedule never forces a host synchronisation; same elementwise op order as the reference."""
         dev = self.flat.device
         if self.opt.barf_c2f is None:
             return torch.ones(14, dtype=torch.float32, device=dev)
+        if getattr(self, '_band_consts', None) is None:
+            L = torch.tensor([float(self.L_3D)] * self.L_3D + [float(self.L_VIEW)] * self.L_VIEW, device=dev)
+            k = torch.tensor(list(range(self.L_3D)) + list(range(self.L_VIEW)), dtype=torch.float32, device=dev)
+            self._band_consts = (L, k)
+        L, k = self._band_consts
         start, end = self.opt.barf_c2f
-        out = []
-        for L in (self.L_3D, self.L_VIEW):
-            alpha = (self.progress.data - start) / (end - start) * L
-            k = torch.arange(L, dtype=torch.float32, device=dev)
-            out.append((1 - (alpha - k).clamp_(min=0, max=1).mul_(math.pi).cos_()) / 2)
-        return torch.cat(out)
+        alpha = (self.progress.data - start) / (end - start) * L
+        return (1 - (alpha - k).clamp_(min=0, max=1).mul_(math.pi).cos_()) / 2
 
     def _workspace(self, R, S):
         ws = self._ws.get((R, S))

@@ -180,23 +180,40 @@ __global__ __launch_bounds__(256) void k_nerf_rgb_bwd(const float* __restrict__ 
 }
 
 // density head backward: column 256 of the last feature layer's output gradient carries d raw; wd / bd gradients.
+// Work-group = 4 wavefronts x 64 lanes; a lane owns 4 consecutive columns (float4 loads), a wavefront every 4th row of the
+// strip, so 4 rows are in flight per work-group and the 1 KB rows are read with 16-byte accesses.
+#define NERF_DSTRIP 512
 __global__ __launch_bounds__(256) void k_nerf_density_bwd(const float* __restrict__ a6, const float* __restrict__ raw,
                                                           const float* __restrict__ g_density, int M,
                                                           float* __restrict__ dY7, float* __restrict__ wdbar,
                                                           float* __restrict__ bdbar) {
-  const int m0 = blockIdx.x * NERF_STRIP;
+  __shared__ float4 red[4][64];
+  __shared__ float redb[4];
+  const int m0 = blockIdx.x * NERF_DSTRIP;
   if (m0 >= M) return;
-  const int k = threadIdx.x;
-  float acc = 0.f, bacc = 0.f;
-  const int mend = min(m0 + NERF_STRIP, M);
-  for (int m = m0; m < mend; ++m) {
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bacc = 0.f;
+  const int mend = min(m0 + NERF_DSTRIP, M);
+#pragma unroll 4
+  for (int m = m0 + wid; m < mend; m += 4) {
     const float g = g_density[m] * nerf_dsoftplus(raw[m]);
-    acc += g * a6[(size_t)m * 256 + k];
-    if (k < 32) dY7[(size_t)m * 288 + 256 + k] = (k == 0) ? g : 0.f;
+    const float4 x = *reinterpret_cast<const float4*>(a6 + (size_t)m * 256 + lane * 4);
+    acc.x += g * x.x; acc.y += g * x.y; acc.z += g * x.z; acc.w += g * x.w;
+    if (lane < 32) dY7[(size_t)m * 288 + 256 + lane] = (lane == 0) ? g : 0.f;
     bacc += g;
   }
-  atomicAdd(&wdbar[k], acc);
-  if (k == 0) atomicAdd(&bdbar[0], bacc);
+  red[wid][lane] = acc;
+  if (lane == 0) redb[wid] = bacc;
+  __syncthreads();
+  if (wid == 0) {
+    const float4 a = red[0][lane], b = red[1][lane], c = red[2][lane], d = red[3][lane];
+    atomicAdd(&wdbar[lane * 4 + 0], a.x + b.x + c.x + d.x);
+    atomicAdd(&wdbar[lane * 4 + 1], a.y + b.y + c.y + d.y);
+    atomicAdd(&wdbar[lane * 4 + 2], a.z + b.z + c.z + d.z);
+    atomicAdd(&wdbar[lane * 4 + 3], a.w + b.w + c.w + d.w);
+    if (lane == 0) atomicAdd(&bdbar[0], redb[0] + redb[1] + redb[2] + redb[3]);
+  }
 }
 
 // dst[c * ldd + r] = src[r * lds + c]
@@ -206,6 +223,19 @@ __global__ __launch_bounds__(256) void k_nerf_transpose(const float* __restrict_
   if (i >= rows * cols) return;
   const int c = i / rows, r = i - c * rows;
   dst[(size_t)c * ldd + r] = src[(size_t)r * lds + c];
+}
+
+// all nine weight matrices of the backward pass in ONE launch: blockIdx.y selects the matrix
+struct NerfTransposeJobs { const float* src[9]; float* dst[9]; int lds[9], rows[9], cols[9], ldd[9]; };
+__global__ __launch_bounds__(256) void k_nerf_transpose_all(NerfTransposeJobs J) {
+  const int q = blockIdx.y;
+  const int rows = J.rows[q], cols = J.cols[q];
+  const float* __restrict__ src = J.src[q];
+  float* __restrict__ dst = J.dst[q];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += gridDim.x * blockDim.x) {
+    const int c = i / rows, r = i - c * rows;
+    dst[(size_t)c * J.ldd[q] + r] = src[(size_t)r * J.lds[q] + c];
+  }
 }
 
 // column 256 of the transposed last feature layer = density row wd ; columns 257..287 stay zero
@@ -531,12 +561,16 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
   float* R0T = WT[7] + 256 * 288;                  // [288][128]
   dim3 b(256);
   // transposed weights for the data-gradient GEMMs (2 MB, L2 resident)
-  for (int l = 0; l < 7; ++l)
-    hipLaunchKernelGGL(k_nerf_transpose, dim3(pp_div_up(256 * NERF_IN_LD[l], 256)), b, 0, st, params + L.w[l], NERF_IN_LD[l],
-                       256, NERF_IN_LD[l], WT[l], 256);
-  hipLaunchKernelGGL(k_nerf_transpose, dim3(256), b, 0, st, params + L.w[7], 256, 256, 256, WT[7], 288);
+  {
+    NerfTransposeJobs J;
+    for (int l = 0; l < 8; ++l) {
+      J.src[l] = params + L.w[l]; J.dst[l] = WT[l]; J.lds[l] = NERF_IN_LD[l]; J.rows[l] = 256; J.cols[l] = NERF_IN_LD[l];
+      J.ldd[l] = (l == 7) ? 288 : 256;
+    }
+    J.src[8] = params + L.r0; J.dst[8] = R0T; J.lds[8] = 288; J.rows[8] = 128; J.cols[8] = 288; J.ldd[8] = 128;
+    hipLaunchKernelGGL(k_nerf_transpose_all, dim3(64, 9), b, 0, st, J);
+  }
   hipLaunchKernelGGL(k_nerf_wd_column, dim3(1), b, 0, st, params + L.wd, WT[7]);
-  hipLaunchKernelGGL(k_nerf_transpose, dim3(pp_div_up(128 * 288, 256)), b, 0, st, params + L.r0, 288, 128, 288, R0T, 128);
 
   // colour head
   float* dH = Q;                                   // [M][128]
@@ -547,7 +581,7 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
   nerf_gemm<EPI_PLAIN>(st, dHsum, 128, R0T + 256 * 128, 128, 128, 32, nullptr, nullptr, 0, dView, 32, count, R);
   // last feature layer: columns 0..255 through the colour head, column 256 from the density
   nerf_gemm<EPI_MASK>(st, dH, 128, R0T, 128, 128, 256, nullptr, A.a[7], 288, P, 288, count, M);
-  hipLaunchKernelGGL(k_nerf_density_bwd, dim3(pp_div_up(M, NERF_STRIP)), b, 0, st, A.a[6], A.raw, g_density_samples, M, P,
+  hipLaunchKernelGGL(k_nerf_density_bwd, dim3(pp_div_up(M, NERF_DSTRIP)), b, 0, st, A.a[6], A.raw, g_density_samples, M, P,
                      params_grad + L.wd, params_grad + L.bd);
   nerf_gemm_tn(st, P, 288, 256, A.a[6], 256, 256, params_grad + L.w[7], params_grad + L.b[7], count, M);
   nerf_gemm<EPI_MASK>(st, P, 288, WT[7], 288, 288, 256, nullptr, A.a[6], 256, Q, 256, count, M);

@@ -249,3 +249,15 @@ def test_scene_renderer_matches_reference_render(label, it):
             assert_close(ret[k], d[f'{label}.{k}'], rtol=2e-3, atol=5e-4, name=k)
         else:
             assert_close(ret[k], d[f'{label}.{k}'], rtol=5e-5, atol=5e-6, name=k)
+
+
+def test_scene_band_schedule_follows_in_place_progress_updates():
+    """The trainer moves the coarse-to-fine window with `progress.data.fill_` (renderer.py:399-402): the next forward must
+    see it (no stale cache), and the weights equal the oracle's window."""
+    from oracle import scene_nerf as SN
+    net, opt = _net(progress=0.45)
+    for p in (0.45, 0.58, 0.9):
+        net.progress.data.fill_(p)
+        w = net.band_weights().cpu()
+        ref = torch.cat([SN.band_weights(np.float32(p).item(), tuple(opt.barf_c2f), 10), SN.band_weights(np.float32(p).item(), tuple(opt.barf_c2f), 4)])
+        assert_close(w, ref, rtol=1e-5, atol=1e-6, name=f'bands at {p}')
