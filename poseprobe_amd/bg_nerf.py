@@ -380,25 +380,38 @@ def photometric_loss(rgb, image, huber=True):
     return torch.nn.functional.mse_loss(rgb, image)
 
 
-class SceneEngine:
-    """One optimisation step of the scene branch without autograd bookkeeping: forward, photometric loss, backward and one
-    fused Adam update over the packed parameter block (renderer.py:420-423 train_iteration + the optimiser step of
-    lib/recon_scene.py:765).  Ray gradients are returned for the caller's pose chain."""
+class _NetState:
+    """Gradient block and Adam moments of one packed network."""
 
-    def __init__(self, net, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, net):
         self.net = net
-        self.lr, self.betas, self.eps = lr, betas, eps
         self.grad = torch.zeros_like(net.flat)
         self.m, self.v = torch.zeros_like(net.flat), torch.zeros_like(net.flat)
-        self.step_count = 0
-        dev = net.flat.device
-        self.seg_end = torch.tensor([net.flat.numel()], dtype=torch.int32, device=dev)
-        self.seg_lr = torch.tensor([lr], dtype=torch.float32, device=dev)
+        self.seg_end = torch.tensor([net.flat.numel()], dtype=torch.int32, device=net.flat.device)
+        self.steps = 0               # optimiser steps this network has taken (torch.optim.Adam keeps `step` per parameter)
+        self.has_grad = False
 
-    def forward_backward(self, center, ray, depth, image):
-        """center, ray [R,3]; depth [R,S]; image [R,3] -> (loss, g_center, g_ray); parameter gradients are accumulated into
-        self.grad, which optimizer_step() consumes and re-zeroes."""
-        net = self.net
+
+class SceneEngine:
+    """One optimisation step of the scene branch without autograd bookkeeping: forward, photometric loss, backward and one
+    fused Adam update per packed parameter block (renderer.py:420-423 train_iteration + the optimiser step of
+    lib/recon_scene.py:765).  With `net_fine` and `fine=True` the step is the reference's hierarchical one
+    (renderer.py:586-611): the fine network runs on the union of the coarse samples and inverse-transform samples of the
+    coarse weights, `loss = huber(rgb) + huber(rgb_fine)` (base_losses.py:304-307), both networks receive gradients.
+    Ray gradients (sum over the passes) are returned for the caller's pose chain."""
+
+    def __init__(self, net, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, net_fine=None):
+        self.net, self.net_fine = net, net_fine
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.states = [_NetState(net)] + ([_NetState(net_fine)] if net_fine is not None else [])
+        self.grad, self.m, self.v = self.states[0].grad, self.states[0].m, self.states[0].v
+        self.step_count = 0
+        self.seg_lr = torch.tensor([lr], dtype=torch.float32, device=net.flat.device)
+
+    @staticmethod
+    def _pass(state, center, ray, depth, image):
+        """One network: forward, compositing, 2 * huber(delta = 0.5, mean), backward.  -> loss, g_center, g_ray, weights."""
+        net = state.net
         R, S = depth.shape
         ws = net._workspace(R, S)
         f = dict(dtype=torch.float32, device=depth.device)
@@ -413,28 +426,52 @@ class SceneEngine:
         ops.nerf_fwd(net.flat, center, ray, depth, net.band_weights(), ws.count, R, S, ws.acts, b['rgb_s'], b['dens'])
         ops.nerf_composite_fwd(b['rgb_s'], b['dens'], depth, ray, R, S, white, b['rgb'], b['d'], b['op'], b['w'], b['cum'],
                                b['rv'], b['dv'])
-        # 2 * huber(delta = 0.5, mean) and its gradient on the [R,3] colours (tiny, per-ray)
-        diff = b['rgb'] - image
+        diff = b['rgb'] - image                                   # tiny, per-ray: the loss and its gradient on [R,3] colours
         ad = diff.abs()
         loss = 2. * torch.where(ad <= 0.5, 0.5 * diff * diff, 0.5 * (ad - 0.25)).mean()
         g_rgb = (2. / diff.numel()) * diff.clamp(-0.5, 0.5)
         ops.nerf_composite_bwd(b['rgb_s'], b['dens'], depth, ray, b['w'], R, S, white, g_rgb.contiguous(), b['zero_r'],
                                b['zero_r'], None, b['g_rgb_s'], b['g_dens'], b['g_ray_c'])
         ops.nerf_bwd(net.flat, ray, depth, ws.count, R, S, ws.acts, b['rgb_s'], b['g_rgb_s'], b['g_dens'], ws.scratch,
-                     self.grad, b['g_center'], b['g_ray'])
-        return loss, b['g_center'], b['g_ray'] + b['g_ray_c']
+                     state.grad, b['g_center'], b['g_ray'])
+        state.has_grad = True
+        return loss, b['g_center'], b['g_ray'] + b['g_ray_c'], b['w']
+
+    def forward_backward(self, center, ray, depth, image, fine=False, depth_range=None, fine_grid=None):
+        """center, ray [R,3]; depth [R,S]; image [R,3] -> (loss, g_center, g_ray); parameter gradients are accumulated into the
+        networks' gradient blocks, which optimizer_step() consumes and re-zeroes.  fine=True adds the second pass
+        (`depth_range` required; `fine_grid` [Nf + 1] replays the sampler's uniform draw)."""
+        loss, g_center, g_ray, w = self._pass(self.states[0], center, ray, depth, image)
+        if fine:
+            if self.net_fine is None or depth_range is None:
+                raise ValueError('SceneEngine: fine=True needs net_fine and depth_range')
+            opt = self.net.opt
+            S = depth.shape[1]
+            det = not opt.nerf.sample_stratified
+            fine_t = sample_depth_from_pdf(w[None], S, opt.nerf.sample_intvs_fine, depth_range, det=det, grid=fine_grid)
+            depth_f = torch.cat([depth, fine_t[0, :, :, 0]], dim=1).sort(dim=1).values.contiguous()
+            loss_f, gc_f, gr_f, _ = self._pass(self.states[1], center, ray, depth_f, image)
+            loss, g_center, g_ray = loss + loss_f, g_center + gc_f, g_ray + gr_f
+        return loss, g_center, g_ray
 
     def optimizer_step(self):
-        """torch.optim.Adam semantics (lib/utils.py:294-296); also re-zeroes the gradient block for the next step."""
+        """torch.optim.Adam semantics (lib/utils.py:294-299); also re-zeroes the gradient blocks for the next step.  Like
+        torch's optimiser, a network that received no gradient this iteration (the fine one before its start) is skipped and
+        its step counter - hence its bias correction - does not advance."""
         self.step_count += 1
-        ops.adam_flat(self.net.flat, self.grad, self.m, self.v, self.seg_end, self.seg_lr, 1.0, self.betas[0], self.betas[1],
-                      self.eps, self.step_count, True)
+        for st in self.states:
+            if not st.has_grad:
+                continue
+            st.steps += 1
+            st.has_grad = False
+            ops.adam_flat(st.net.flat, st.grad, st.m, st.v, st.seg_end, self.seg_lr, 1.0, self.betas[0], self.betas[1],
+                          self.eps, st.steps, True)
 
     def set_lr(self, lr):
         self.lr = lr
         self.seg_lr.fill_(lr)
 
-    def step(self, center, ray, depth, image):
-        loss, g_center, g_ray = self.forward_backward(center, ray, depth, image)
+    def step(self, center, ray, depth, image, **kw):
+        loss, g_center, g_ray = self.forward_backward(center, ray, depth, image, **kw)
         self.optimizer_step()
         return loss, g_center, g_ray

@@ -14,9 +14,9 @@ from . import bg_nerf, ops
 
 
 class DualBranchEngine:
-    def __init__(self, obj_engine, scene_net, lr_scene=1e-3, depth_range=(0.5, 3.0)):
+    def __init__(self, obj_engine, scene_net, lr_scene=1e-3, depth_range=(0.5, 3.0), scene_net_fine=None):
         self.obj = obj_engine
-        self.scene = bg_nerf.SceneEngine(scene_net, lr=lr_scene)
+        self.scene = bg_nerf.SceneEngine(scene_net, lr=lr_scene, net_fine=scene_net_fine)
         self.depth_range = depth_range
         e = obj_engine
         self._se3_tmp = torch.zeros_like(e.se3_grad)
@@ -34,9 +34,9 @@ class DualBranchEngine:
         center = c2w[:, None, :, 3].expand_as(ray)
         return center, ray, dir_cam
 
-    def forward_backward(self, ray_idx, jitter, global_step, pixels, image, depth_rand=None):
+    def forward_backward(self, ray_idx, jitter, global_step, pixels, image, depth_rand=None, fine=False, fine_grid=None):
         """ray_idx / jitter: the object branch's batch (engine.TrainEngine.train_step); pixels [N, 2] + image [V, N, 3]: the
-        scene branch's batch; depth_rand [V, N, S, 1] optionally replays the stratified jitter.  On return every gradient
+        scene branch's batch; depth_rand [V, N, S, 1] / fine_grid [Nf + 1] optionally replay the samplers' draws.  On return every gradient
         buffer (object engine's k0 / MLPs / se3 - the pose gradient of BOTH branches - and the scene engine's block) is
         filled; the object engine's gradients must be zero on entry (its optimiser kernels leave them so)."""
         e, sc = self.obj, self.scene
@@ -50,7 +50,8 @@ class DualBranchEngine:
             jit = depth_rand + torch.arange(S, device=pixels.device)[None, None, :, None].float()
             depth = jit / S * (self.depth_range[1] - self.depth_range[0]) + self.depth_range[0]
         loss_bg, g_center, g_ray = sc.forward_backward(center.reshape(V * N, 3).contiguous(), ray.reshape(V * N, 3).contiguous(),
-                                                       depth.reshape(V * N, S).contiguous(), image.reshape(V * N, 3))
+                                                       depth.reshape(V * N, S).contiguous(), image.reshape(V * N, 3),
+                                                       fine=fine, depth_range=self.depth_range, fine_grid=fine_grid)
         # fold the ray gradients into d L_bg / d c2w and through the object engine's pose Jacobian
         g_ray, g_center = g_ray.view(V, N, 3), g_center.view(V, N, 3)
         g_c2w = torch.cat([torch.einsum('vni,vnj->vij', g_ray, dir_cam), g_center.sum(1)[..., None]], dim=-1).contiguous()
@@ -59,8 +60,10 @@ class DualBranchEngine:
         self.last_scene_loss = loss_bg
         return out, loss_bg
 
-    def train_step(self, ray_idx, jitter, global_step, pixels, image, depth_rand=None, optimize_pose=True):
-        out = self.forward_backward(ray_idx, jitter, global_step, pixels, image, depth_rand)
+    def train_step(self, ray_idx, jitter, global_step, pixels, image, depth_rand=None, optimize_pose=True, fine=False,
+                   fine_grid=None):
+        """fine=True: the scene branch also runs its fine network (after ratio_start_fine_sampling_at_x of the schedule)."""
+        out = self.forward_backward(ray_idx, jitter, global_step, pixels, image, depth_rand, fine, fine_grid)
         self.obj.grad_scale = 1.0
         self.obj.optimizer_step(optimize_pose, grad_scale=1.0)
         self.scene.optimizer_step()
