@@ -1,0 +1,135 @@
+"""Minimal counterpart of the reference's joint training loop (lib/recon_scene.py:534-791) around the two HIP engines: the
+schedules that decide WHAT a step does, the batch samplers and the scene branch's snapshot file.  Not a re-implementation of
+the trainer (view selection, PnP re-initialisation, matching, logging and evaluation stay with the reference): it exists to
+drive `joint.DualBranchEngine` the way `scene_rep_reconstruction` drives the two models, and to read / write the files that
+loop reads / writes.
+
+Schedules (all pure functions of the step, unit-tested on the CPU):
+  * scene learning rate   ExponentialLR from `optim.lr` to `optim.lr_end` over `max_iter` (lib/utils.py:300-313,
+                          default_config.py:176-180),
+  * coarse-to-fine window `progress = iteration_nerf / max_iter` written into both NeRFs (renderer.py:399-402),
+  * fine network          from `ratio_start_fine_sampling_at_x * max_iter` on (renderer.py:580-584),
+  * pose refinement       while `step < ratio_end_joint_nerf_pose_refinement * max_iter` (sparf.py:33, recon_scene.py:770).
+"""
+import os
+
+import torch
+
+from . import bg_nerf
+from .joint import DualBranchEngine
+
+
+def scene_lr(step, lr=1e-3, lr_end=1e-4, max_iter=60000):
+    """Learning rate the scheduler holds AFTER `step` optimiser steps."""
+    gamma = (lr_end / lr) ** (1.0 / max_iter)
+    return lr * gamma ** step
+
+
+def fine_phase(step, max_iter, ratio_start_fine=0.3, fine_sampling=True):
+    return bool(fine_sampling) and not (ratio_start_fine is not None and step < max_iter * ratio_start_fine)
+
+
+def pose_phase(step, max_iter, ratio_end_pose=0.3):
+    return step < max_iter * ratio_end_pose
+
+
+def c2f_progress(iteration_nerf, max_iter):
+    return iteration_nerf / max_iter
+
+
+class DualBranchTrainer:
+    def __init__(self, obj_engine, opt, max_iter=60000, lr=1e-3, lr_end=1e-4, ratio_start_fine=0.3, ratio_end_pose=0.3,
+                 depth_range=(0.5, 3.0), seed=0):
+        self.opt, self.max_iter = opt, max_iter
+        self.lr, self.lr_end = lr, lr_end
+        self.ratio_start_fine, self.ratio_end_pose = ratio_start_fine, ratio_end_pose
+        dev = obj_engine.dev
+        self.nerf = bg_nerf.NeRF(opt, device=dev)
+        self.nerf_fine = bg_nerf.NeRF(opt, is_fine_network=True, device=dev) if opt.nerf.fine_sampling else None
+        self.joint = DualBranchEngine(obj_engine, self.nerf, lr_scene=lr, depth_range=depth_range, scene_net_fine=self.nerf_fine)
+        self.iteration = 0            # == the reference's Graph.iteration_nerf
+        self.gen = torch.Generator(device=dev).manual_seed(seed)
+        self.dev = dev
+
+    # ---- batches (recon_scene.py:598-606 for the object branch, sampling_strategies.py:132-170 for the scene branch) ------
+    def sample_batch(self):
+        e = self.joint.obj
+        n_total = e.V * e.H * e.W
+        ray_idx = torch.randperm(n_total, device=self.dev, generator=self.gen)[:e.N].to(torch.int32)
+        jitter = torch.rand(e.N, device=self.dev, generator=self.gen)
+        n_pix = self.opt.nerf.rand_rays // e.V
+        flat = torch.randperm(e.H * e.W, device=self.dev, generator=self.gen)[:n_pix]
+        py, px = flat // e.W, flat % e.W
+        image = e.images[:, py, px]                                    # [V, n_pix, 3] ground-truth colours at those pixels
+        pixels = torch.stack([px.float() + 0.5, py.float() + 0.5], dim=-1)
+        return ray_idx, jitter, pixels, image
+
+    def train_step(self, global_step):
+        """One iteration of the joint loop; returns (object-branch summary, scene loss)."""
+        self.iteration += 1
+        fine = fine_phase(global_step, self.max_iter, self.ratio_start_fine, self.nerf_fine is not None)
+        ray_idx, jitter, pixels, image = self.sample_batch()
+        out = self.joint.train_step(ray_idx, jitter, global_step, pixels, image, fine=fine,
+                                    optimize_pose=pose_phase(global_step, self.max_iter, self.ratio_end_pose))
+        self.joint.scene.set_lr(scene_lr(self.iteration, self.lr, self.lr_end, self.max_iter))
+        p = c2f_progress(self.iteration, self.max_iter)                # takes effect from the next iteration (renderer.py:399)
+        self.nerf.progress.data.fill_(p)
+        if self.nerf_fine is not None:
+            self.nerf_fine.progress.data.fill_(p)
+        return out
+
+    # ---- `model_last.pth.tar` (renderer.py:1028-1051 save_snapshot, recon_scene.py:827-838 load) ----------------------------
+    def _adam_state_dict(self):
+        """torch.optim.Adam.state_dict() layout over [nerf.parameters(), nerf_fine.parameters()] (lib/utils.py:294-299)."""
+        state, groups, idx = {}, [], 0
+        for st in self.joint.scene.states:
+            ids = []
+            views_m, views_v = st.net._views(st.m), st.net._views(st.v)
+            for m, v in zip(views_m, views_v):
+                if st.steps > 0:
+                    state[idx] = {'step': torch.tensor(float(st.steps)), 'exp_avg': m.detach().clone().cpu(),
+                                  'exp_avg_sq': v.detach().clone().cpu()}
+                ids.append(idx)
+                idx += 1
+            ids.append(idx)                                            # `progress`: a Parameter without gradient, no state
+            idx += 1
+            groups.append({'lr': float(self.joint.scene.lr), 'betas': (0.9, 0.999), 'eps': 1e-8, 'weight_decay': 0,
+                           'amsgrad': False, 'params': ids})
+        return {'state': state, 'param_groups': groups}
+
+    def state_dict(self):
+        sd = {'nerf.' + k: v.detach().clone().cpu() for k, v in self.nerf.state_dict().items()}
+        if self.nerf_fine is not None:
+            sd.update({'nerf_fine.' + k: v.detach().clone().cpu() for k, v in self.nerf_fine.state_dict().items()})
+        return sd
+
+    def save_snapshot(self, directory, filename='model_last.pth.tar'):
+        os.makedirs(directory, exist_ok=True)
+        e = self.joint.obj
+        torch.save({'current_pose': e.w2c.detach().clone().cpu(), 'epoch': 0, 'iteration': self.iteration,
+                    'iteration_nerf': self.iteration, 'state_dict': self.state_dict(), 'best_val': None,
+                    'epoch_of_best_val': None, 'optimizer': self._adam_state_dict(),
+                    'scheduler': {'last_epoch': self.iteration, 'gamma': (self.lr_end / self.lr) ** (1.0 / self.max_iter),
+                                  '_last_lr': [float(self.joint.scene.lr)] * len(self.joint.scene.states)}},
+                   os.path.join(directory, filename))
+
+    def load_snapshot(self, path):
+        """Accepts a file written by save_snapshot or by the reference's Graph.save_snapshot (tensors only are read)."""
+        ck = torch.load(path, map_location='cpu', weights_only=True)
+        sd = ck['state_dict']
+        nets = [('nerf.', self.nerf)] + ([('nerf_fine.', self.nerf_fine)] if self.nerf_fine is not None else [])
+        for prefix, net in nets:
+            net.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}, strict=True)
+        self.iteration = int(ck['iteration_nerf'])
+        opt_state, groups = ck['optimizer']['state'], ck['optimizer']['param_groups']
+        for st, grp in zip(self.joint.scene.states, groups):
+            ids = grp['params'][:-1]
+            st.m.zero_(), st.v.zero_()
+            st.steps = 0
+            for i, m, v in zip(ids, st.net._views(st.m), st.net._views(st.v)):
+                if i in opt_state:
+                    m.copy_(opt_state[i]['exp_avg'])
+                    v.copy_(opt_state[i]['exp_avg_sq'])
+                    st.steps = int(opt_state[i]['step'])
+        self.joint.scene.set_lr(scene_lr(self.iteration, self.lr, self.lr_end, self.max_iter))
+        return ck.get('current_pose')

@@ -92,3 +92,42 @@ def test_joint_train_steps_run_and_reduce_both_losses():
     assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0], losses
     assert float((eng.se3 - se3_before).abs().max()) > 0           # poses moved (views other than the fixed first one)
     assert float((eng.se3 - se3_before)[0].abs().max()) == 0.0
+
+
+def test_trainer_counterpart_schedules_and_snapshot(tmp_path):
+    """DualBranchTrainer: the fine network and the end of pose refinement start where the schedule says, the coarse-to-fine
+    window and the learning rate follow the iteration, and `model_last.pth.tar` round-trips (reference key layout)."""
+    from poseprobe_amd import bg_nerf
+    from poseprobe_amd.trainer import DualBranchTrainer, scene_lr
+    d = load('forward_g24_s10.npz')
+    eng, _ = build_engine(d)
+    eng.zero_grads()
+    opt = bg_nerf.default_options(sample_intvs=16)
+    opt.nerf.fine_sampling, opt.nerf.sample_intvs_fine, opt.nerf.rand_rays = True, 16, 96
+    torch.manual_seed(2)
+    tr = DualBranchTrainer(eng, opt, max_iter=10, ratio_start_fine=0.3, ratio_end_pose=0.3)
+    se3_hist = []
+    for step in range(6):
+        _, loss_bg = tr.train_step(step)
+        se3_hist.append(eng.se3.clone())
+        assert np.isfinite(float(loss_bg))
+    st_c, st_f = tr.joint.scene.states
+    assert st_c.steps == 6 and st_f.steps == 3                          # fine network from step 3 = 0.3 * max_iter on
+    assert not torch.equal(se3_hist[2], se3_hist[1]) and torch.equal(se3_hist[5], se3_hist[2])   # poses frozen from step 3
+    assert abs(float(tr.nerf.progress) - 0.6) < 1e-6 and abs(float(tr.nerf_fine.progress) - 0.6) < 1e-6
+    assert abs(float(tr.joint.scene.seg_lr) - scene_lr(6, 1e-3, 1e-4, 10)) < 1e-9
+    tr.save_snapshot(str(tmp_path))
+    ck = torch.load(str(tmp_path / 'model_last.pth.tar'), map_location='cpu', weights_only=True)
+    assert set(ck) >= {'current_pose', 'iteration', 'iteration_nerf', 'state_dict', 'optimizer', 'scheduler'}
+    assert ck['state_dict']['nerf.mlp_feat.7.weight'].shape == (257, 256) and ck['state_dict']['nerf_fine.mlp_rgb.0.weight'].shape == (128, 283)
+    ref_opt = torch.optim.Adam([torch.nn.Parameter(v.clone()) for k, v in ck['state_dict'].items() if k.startswith('nerf.')], lr=1e-3)
+    ref_opt.add_param_group(dict(params=[torch.nn.Parameter(v.clone()) for k, v in ck['state_dict'].items() if k.startswith('nerf_fine.')]))
+    ref_opt.load_state_dict(ck['optimizer'])                           # torch accepts it as an Adam state of those two groups
+
+    eng2, _ = build_engine(d)
+    tr2 = DualBranchTrainer(eng2, opt, max_iter=10)
+    tr2.load_snapshot(str(tmp_path / 'model_last.pth.tar'))
+    assert tr2.iteration == 6
+    for a, b in zip(tr.joint.scene.states, tr2.joint.scene.states):
+        assert torch.equal(a.net.flat, b.net.flat) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v) and a.steps == b.steps
+    assert abs(float(tr2.nerf.progress) - 0.6) < 1e-6

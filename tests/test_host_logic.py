@@ -83,3 +83,15 @@ def test_committed_bench_record_follows_the_contract():
     c = d['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and isinstance(c['sample'], str)
     assert abs(d['value'] - 1024 * d['n_gpus'] / (d['ms_per_step'] * 1e-3)) < 1e-3 * d['value']
+
+
+def test_joint_loop_schedules():
+    """Pure schedule functions of the trainer counterpart (lib/utils.py:300-313, renderer.py:580-584, sparf.py:33)."""
+    from poseprobe_amd import trainer as T
+    assert abs(T.scene_lr(0, 1e-3, 1e-4, 1000) - 1e-3) < 1e-12
+    assert abs(T.scene_lr(1000, 1e-3, 1e-4, 1000) - 1e-4) < 1e-12
+    assert abs(T.scene_lr(500, 1e-3, 1e-4, 1000) - 10 ** -3.5) < 1e-12
+    assert not T.fine_phase(299, 1000, 0.3) and T.fine_phase(300, 1000, 0.3)
+    assert T.fine_phase(0, 1000, None) and not T.fine_phase(900, 1000, 0.3, fine_sampling=False)
+    assert T.pose_phase(299, 1000, 0.3) and not T.pose_phase(300, 1000, 0.3)
+    assert T.c2f_progress(250, 1000) == 0.25
