@@ -77,44 +77,79 @@ def cpu_baseline(G, H, W, V, n_rand, views, budget_s=20.0):
             break
     t = float(np.median(times[1:])) if len(times) > 1 else times[0]
     used = torch.get_num_threads()
+    scene = cpu_baseline_scene(V, used)
     torch.set_num_threads(threads_before)
     return {'value': n_rand / t, 'unit': 'rays/s', 'cores': used, 'kind': 'port',
             'sample': f'{len(times)} oracle train steps (torch-CPU fp32, {n_rand} rays, {G}^3 grid, first step dropped), '
-                      f'median {t:.3f} s/step'}
+                      f'median {t:.3f} s/step', 'scene_branch': scene}
+
+
+def cpu_baseline_scene(V, threads, n_pix=341, S=128, reps=3):
+    """The scene branch's coarse pass (forward, loss, backward) of the oracle on the same host cores, beside `dual_branch`."""
+    from oracle import scene_nerf as SN
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    R = V * n_pix
+    P = {}
+    dims = [(256, 63)] + [(256, 256)] * 3 + [(256, 319)] + [(256, 256)] * 2 + [(257, 256)]
+    for i, (o, k) in enumerate(dims):
+        P[f'mlp_feat.{i}.weight'] = (torch.randn(o, k, generator=g) * (2.0 / k) ** 0.5).requires_grad_(True)
+        P[f'mlp_feat.{i}.bias'] = torch.zeros(o, requires_grad=True)
+    for i, (o, k) in enumerate([(128, 283), (3, 128)]):
+        P[f'mlp_rgb.{i}.weight'] = (torch.randn(o, k, generator=g) * (2.0 / k) ** 0.5).requires_grad_(True)
+        P[f'mlp_rgb.{i}.bias'] = torch.zeros(o, requires_grad=True)
+    center, ray = torch.randn(R, 3, generator=g) * 0.3, torch.randn(R, 3, generator=g)
+    depth = (torch.rand(R, S, generator=g) + torch.arange(S)) / S * 2.5 + 0.5
+    image = torch.rand(R, 3, generator=g)
+    times = []
+    for _ in range(reps):
+        t0 = time.time()
+        loss = SN.photometric_loss(SN.render(P, center, ray, depth, 0.5, (0.4, 0.7))['rgb'], image)
+        loss.backward()
+        times.append(time.time() - t0)
+    t = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    return {'value': R / t, 'unit': 'rays/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{reps} oracle coarse passes (torch-CPU fp32, {R} rays x {S} samples, forward + loss + backward, first '
+                      f'dropped), median {t:.3f} s'}
 
 
 def dual_branch_leg(eng, idx_all, jit_all, gs, N, V, H, W, object_ms, dev, steps=20, warmup=3):
     """Informative second measurement (never `value`): the same object-branch step plus the scene branch of the reference's
     joint loop (lib/recon_scene.py:639-649): rand_rays // V pixels per view x 128 stratified samples through the 8 x 256
-    NeRF, 2 * huber loss, backward, Adam, poses shared through the object engine's pose Jacobian."""
+    NeRF, 2 * huber loss, backward, Adam, poses shared through the object engine's pose Jacobian - first the coarse-only phase
+    (the first 30 % of the schedule), then the hierarchical phase (coarse + fine network on 128 + 128 samples)."""
     from poseprobe_amd import bg_nerf
     from poseprobe_amd.joint import DualBranchEngine
     opt = bg_nerf.default_options(sample_intvs=128)
+    opt.nerf.fine_sampling, opt.nerf.sample_intvs_fine = True, 128
     torch.manual_seed(0)
-    net = bg_nerf.NeRF(opt, device=dev)
-    net.progress.data.fill_(0.5)
-    joint = DualBranchEngine(eng, net, lr_scene=1e-3, depth_range=(0.5, 3.0))
+    nets = [bg_nerf.NeRF(opt, device=dev), bg_nerf.NeRF(opt, is_fine_network=True, device=dev)]
+    for n in nets:
+        n.progress.data.fill_(0.5)
+    joint = DualBranchEngine(eng, nets[0], lr_scene=1e-3, depth_range=(0.5, 3.0), scene_net_fine=nets[1])
     n_pix, S = opt.nerf.rand_rays // V, 128
     g = torch.Generator().manual_seed(1)
     px = [(torch.rand(n_pix, 2, generator=g) * torch.tensor([W - 1., H - 1.])).to(dev) for _ in range(steps + warmup)]
     img = torch.rand(V, n_pix, 3, generator=g).to(dev)
     n_avail = idx_all.shape[0]
-    for s in range(warmup):
-        joint.train_step(idx_all[s % n_avail], jit_all[s % n_avail], gs + s, px[s], img)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(warmup, warmup + steps):
-        joint.train_step(idx_all[s % n_avail], jit_all[s % n_avail], gs + s, px[s], img)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    M = V * n_pix * S
-    flop = 3 * 2 * M * (64 * 256 + 6 * 256 * 256 + 320 * 256 + 256 + 288 * 128 + 128 * 3)     # fwd + data grad + weight grad
-    scene_ms = ms - object_ms
-    return {'workload': f'object-branch step + scene branch: {V} x {n_pix} rays x {S} stratified samples, 8x256 NeRF (BARF PE), '
-                        f'2*huber loss, backward, Adam; shared poses, loss = 0.1 L_obj + L_bg',
-            'ms_per_step': ms, 'rays_per_s': (N + V * n_pix) / (ms * 1e-3), 'object_rays': N, 'scene_rays': V * n_pix,
-            'scene_samples': M, 'scene_ms': scene_ms, 'scene_mfma_tflops': flop / (scene_ms * 1e-3) / 1e12,
-            'scene_mfma_frac_of_fp32_peak': flop / (scene_ms * 1e-3) / 1e12 / 157.3, 'n_gpus': 1}
+    fl_sample = 2 * (64 * 256 + 6 * 256 * 256 + 320 * 256 + 256 + 288 * 128 + 128 * 3)       # forward FLOP per sample
+    out = {'workload': f'object-branch step + scene branch: {V} x {n_pix} rays, 8x256 NeRF (BARF PE), 2*huber loss, backward, '
+                       f'Adam; shared poses, loss = 0.1 L_obj + L_bg; coarse phase = {S} stratified samples, hierarchical '
+                       f'phase = coarse + fine network on {S}+{S} samples', 'object_rays': N, 'scene_rays': V * n_pix, 'n_gpus': 1}
+    for label, fine, samples in (('coarse_phase', False, V * n_pix * S), ('hierarchical_phase', True, V * n_pix * 3 * S)):
+        for s in range(warmup):
+            joint.train_step(idx_all[s % n_avail], jit_all[s % n_avail], gs + s, px[s], img, fine=fine)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(warmup, warmup + steps):
+            joint.train_step(idx_all[s % n_avail], jit_all[s % n_avail], gs + s, px[s], img, fine=fine)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        scene_ms = ms - object_ms
+        tf = 3 * fl_sample * samples / (scene_ms * 1e-3) / 1e12                                # fwd + data grad + weight grad
+        out[label] = {'ms_per_step': ms, 'rays_per_s': (N + V * n_pix) / (ms * 1e-3), 'scene_samples': samples,
+                      'scene_ms': scene_ms, 'scene_mfma_tflops': tf, 'scene_mfma_frac_of_fp32_peak': tf / 157.3}
+    return out
 
 
 def main():
