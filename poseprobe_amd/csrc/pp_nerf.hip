@@ -467,7 +467,7 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 static const int NERF_GEMM_WGS = env_int("PP_NERF_GEMM_WGS", 256);     // persistent work-groups per column block (measured: 256 = 512 > 384 > 128)
 static const int NERF_GEMM_WGS_WIDE = 512;   // 128 x 256 tiles: 2 resident per CU (55 KB LDS, ~220 registers)
 static const int NERF_TN_CH = env_int("PP_NERF_TN_CH", 64);           // rows per LDS chunk of the weight-gradient GEMM (32 | 64)
-static const int NERF_TN_WGS = env_int("PP_NERF_TN_WGS", 256);        // row splits of a weight-gradient block (each ends in 64 KB of atomics)
+static const int NERF_TN_WGS = env_int("PP_NERF_TN_WGS", 128);        // row splits of a weight-gradient block: 128 x 4 blocks = 2 work-groups per CU, one round
 
 // PP_NERF_BN=256 selects 128 x 256 tiles (activation tile read once, half the barriers per MFMA).  Measured SLOWER on
 // MI355X (3072 x 128 samples: 15.8 vs 13.8 ms per step): 128 accumulators + operand staging do not fit 256 registers without
