@@ -502,7 +502,8 @@ static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, i
 
 static void nerf_gemm_tn(hipStream_t st, const float* Y, int ldy, int N, const float* X, int ldx, int Kx, float* Wbar,
                          float* bbar, const int32_t* count, int rows) {
-  dim3 g(NERF_TN_WGS, (N / 128) * pp_div_up(Kx, 128)), b(256);
+  const int blocks = (N / 128) * pp_div_up(Kx, 128);
+  dim3 g(NERF_TN_WGS * 4 / blocks, blocks), b(256);       // ~ 4 x NERF_TN_WGS work-groups whatever the block count (2, 3, 4 or 6)
   if (NERF_TN_CH == 64)
     hipLaunchKernelGGL((k_gemm_tn<1, 64>), g, b, 0, st, Y, ldy, X, ldx, Kx, Wbar, ldx, bbar, count, 1, rows);
   else
