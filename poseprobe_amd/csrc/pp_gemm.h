@@ -57,7 +57,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TNW], int r0, in
 // Register budget: the 128-column tile is left to the compiler (it takes 190-280 registers, 1-2 wavefronts per SIMD; capping
 // it at 168 for three work-groups per CU measured 10 % slower); the 256-column tile is capped at 256.
 template <int MODE, int EPI, int COLS, int BM, int BN = 128>
-__global__ __launch_bounds__(256, (BN == 256 ? 2 : 1)) void k_gemm128(const float* __restrict__ A, int lda, const float* __restrict__ W_,
+__global__ __launch_bounds__(256, ((BN == 256 || (EPI == EPI_MASK && BM == 128)) ? 2 : 1)) void k_gemm128(const float* __restrict__ A, int lda, const float* __restrict__ W_,
                                                  int ldw, int K, int Nout_, const float* __restrict__ bias_,
                                                  const float* __restrict__ Xmask_, int ldm, float* __restrict__ C_,
                                                  int ldc, const int32_t* __restrict__ count, int rmul, int rcap) {
