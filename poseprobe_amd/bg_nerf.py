@@ -373,6 +373,21 @@ class SceneRenderer:
         return pred
 
 
+    @torch.no_grad()
+    def render_by_slices(self, opt, pose, H, W, intr, depth_range, iter=None, mode=None):
+        """Full H x W images in slices of `opt.nerf.rand_rays` rays (renderer.py:629-663): per-ray outputs concatenated along
+        the ray axis, `*_fine` keys when the fine pass is active."""
+        keys = ['rgb', 'rgb_var', 'depth', 'depth_var', 'opacity', 'all_cumulated']
+        parts = {}
+        for c in range(0, H * W, opt.nerf.rand_rays):
+            ray_idx = torch.arange(c, min(c + opt.nerf.rand_rays, H * W), device=self.device)
+            ret = self.render(opt, pose, H, W, intr, ray_idx=ray_idx, depth_range=depth_range, iter=iter, mode=mode)
+            for k in keys + [k + '_fine' for k in keys]:
+                if k in ret:
+                    parts.setdefault(k, []).append(ret[k])
+        return Options({k: torch.cat(v, dim=1) for k, v in parts.items()})
+
+
 def photometric_loss(rgb, image, huber=True):
     """Render loss of the branch (training/core/base_losses.py:151-156, :304-305)."""
     if huber:
@@ -454,7 +469,7 @@ class SceneEngine:
             loss, g_center, g_ray = loss + loss_f, g_center + gc_f, g_ray + gr_f
         return loss, g_center, g_ray
 
-    def optimizer_step(self):
+    def optimizer_step(self, grad_scale=1.0):
         """torch.optim.Adam semantics (lib/utils.py:294-299); also re-zeroes the gradient blocks for the next step.  Like
         torch's optimiser, a network that received no gradient this iteration (the fine one before its start) is skipped and
         its step counter - hence its bias correction - does not advance."""
@@ -464,7 +479,7 @@ class SceneEngine:
                 continue
             st.steps += 1
             st.has_grad = False
-            ops.adam_flat(st.net.flat, st.grad, st.m, st.v, st.seg_end, self.seg_lr, 1.0, self.betas[0], self.betas[1],
+            ops.adam_flat(st.net.flat, st.grad, st.m, st.v, st.seg_end, self.seg_lr, grad_scale, self.betas[0], self.betas[1],
                           self.eps, st.steps, True)
 
     def set_lr(self, lr):

@@ -106,6 +106,10 @@ class DistContext:
             t.copy_(self._bucket[o:o + t.numel()].view_as(t))
             o += t.numel()
 
+    def all_reduce_tensor(self, t):
+        """In-place SUM all-reduce of one contiguous tensor (the scene networks' packed gradient blocks)."""
+        dist.all_reduce(t, group=self.group)
+
     def all_gather_rows(self, local, out=None, async_op=False):
         """local [rows, ld] -> out [W, rows, ld] (every rank's buffer, rank order).  Returns (out, work)."""
         if out is None:

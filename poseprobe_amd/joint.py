@@ -64,7 +64,17 @@ class DualBranchEngine:
                    fine_grid=None):
         """fine=True: the scene branch also runs its fine network (after ratio_start_fine_sampling_at_x of the schedule)."""
         out = self.forward_backward(ray_idx, jitter, global_step, pixels, image, depth_rand, fine, fine_grid)
-        self.obj.grad_scale = 1.0
-        self.obj.optimizer_step(optimize_pose, grad_scale=1.0)
-        self.scene.optimizer_step()
+        e = self.obj
+        e.grad_scale = 1.0
+        if e.dist is not None:
+            # ray-sharded data parallelism: the object engine's exchange (DESIGN.md 7) already carries se3_grad, which holds
+            # the pose gradient of BOTH branches; the scene networks add one 2 MB all-reduce each (averaged by grad_scale)
+            e.dist.reduce_gradients(e)
+            for st in self.scene.states:
+                if st.has_grad:
+                    e.dist.all_reduce_tensor(st.grad)
+        e.optimizer_step(optimize_pose, grad_scale=e.grad_scale)
+        self.scene.optimizer_step(grad_scale=e.grad_scale)
+        if e.dist is not None:
+            e.dist.gather_parameters(e)
         return out

@@ -163,3 +163,44 @@ def test_slab_bounds_cover_grid():
             b, e = slab_bounds(X, W, r)
             cover += list(range(b, e))
         assert cover == list(range(X))
+
+
+def _worker_scene(rank, world, port, q):
+    """Scene-branch data parallelism (joint.DualBranchEngine.train_step): each rank's packed gradient block is summed by
+    DistContext.all_reduce_tensor and the Adam step divides by the world size; the replicas stay identical and equal one
+    process that saw the mean gradient."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from poseprobe_amd.dist import DistContext
+    ctx = DistContext()
+    g = torch.Generator().manual_seed(3)
+    p = torch.randn(1000, generator=g)
+    grads = [torch.randn(1000, generator=torch.Generator().manual_seed(50 + r)) for r in range(world)]
+    mine = grads[rank].clone()
+    ctx.all_reduce_tensor(mine)
+    opt_p = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([opt_p], lr=1e-3)
+    opt_p.grad = mine / world                                   # == adam_flat(..., grad_scale = 1 / world)
+    opt.step()
+    q.put((rank, opt_p.detach().clone(), torch.stack(grads).mean(0)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scene_gradient_all_reduce_keeps_replicas_identical():
+    world, port = 2, _free_port()
+    ctxm = mp.get_context('spawn')
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_worker_scene, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.equal(res[0][1], res[1][1])
+    ref_p = torch.randn(1000, generator=torch.Generator().manual_seed(3)).requires_grad_(True)
+    ref = torch.optim.Adam([ref_p], lr=1e-3)
+    ref_p.grad = res[0][2]
+    ref.step()
+    assert torch.allclose(res[0][1], ref_p.detach(), rtol=0, atol=1e-7)

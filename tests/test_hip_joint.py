@@ -131,3 +131,37 @@ def test_trainer_counterpart_schedules_and_snapshot(tmp_path):
     for a, b in zip(tr.joint.scene.states, tr2.joint.scene.states):
         assert torch.equal(a.net.flat, b.net.flat) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v) and a.steps == b.steps
     assert abs(float(tr2.nerf.progress) - 0.6) < 1e-6
+
+
+def test_joint_step_through_rccl_on_one_rank_matches_plain():
+    """The dual-branch step with a DistContext (RCCL, world_size 1): same trajectory as without (atomics budget of the other
+    trajectory tests); exercises the scene networks' all-reduce and the averaged Adam scale."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from poseprobe_amd import bg_nerf
+    from poseprobe_amd.dist import DistContext
+    from poseprobe_amd.joint import DualBranchEngine
+    if not dist.is_initialized():
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    d = load('forward_g8_s10.npz')
+    ray_idx = torch.tensor(d['ray_idx'], dtype=torch.int32, device='cuda')
+    jitter = torch.tensor(d['jitter'], device='cuda')
+    opt = bg_nerf.default_options(sample_intvs=16)
+    pixels, image, rand = _scene_batch(d, 3, 32, 16)
+    finals = []
+    for ctx in (None, DistContext(mode='samples', resync_every=2)):
+        eng, _ = build_engine(d, pose_iters=1000, **({} if ctx is None else {'dist_ctx': ctx}))
+        torch.manual_seed(12)
+        net = bg_nerf.NeRF(opt, device='cuda')
+        net.progress.data.fill_(0.5)
+        joint = DualBranchEngine(eng, net, lr_scene=1e-3)
+        eng.zero_grads()
+        for it in range(3):
+            joint.train_step(ray_idx, jitter, int(d['global_step']) + it, pixels, image, depth_rand=rand)
+        torch.cuda.synchronize()
+        finals.append((eng.se3.clone().cpu(), net.flat.clone().cpu()))
+    assert_close(finals[1][0], finals[0][0], rtol=0, atol=2e-4, name='se3')
+    assert float((finals[1][1] - finals[0][1]).abs().gt(3e-4).float().mean()) < 0.02

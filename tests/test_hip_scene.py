@@ -313,3 +313,26 @@ def test_scene_engine_hierarchical_step_equals_autograd_render():
             assert_close(gv, p.grad, rtol=1e-3, scaled=1e-2, name='g.' + name)
     eng.optimizer_step()
     assert eng.states[0].steps == 2 and eng.states[1].steps == 1 and not torch.equal(sr.nerf_fine.flat, before)
+
+
+def test_scene_render_by_slices_equals_one_pass():
+    """Full-image rendering in ray slices (renderer.py:629-663) == one pass over all pixels (deterministic mid-point samples in
+    eval mode); pixel centres are (x + 0.5, y + 0.5), row-major (utils/camera.py:365-368)."""
+    from poseprobe_amd import bg_nerf, synthetic as syn
+    opt = bg_nerf.default_options(sample_intvs=24)
+    opt.nerf.rand_rays = 100                                  # 16 x 12 = 192 pixels -> two slices, the second one ragged
+    torch.manual_seed(9)
+    sr = bg_nerf.SceneRenderer(opt, device='cuda')
+    sr.nerf.progress.data.fill_(1.0)
+    H, W = 12, 16
+    views = syn.make_views(2, H, W, seed=5)
+    pose = torch.tensor(views['w2c'][:, :3, :4]).float().cuda()
+    intr = torch.tensor(views['Ks']).float().cuda()
+    a = sr.render_by_slices(opt, pose, H, W, intr, depth_range=(0.5, 3.0), mode='eval')
+    b = sr.render(opt, pose, H, W, intr, depth_range=(0.5, 3.0), mode='eval')
+    assert a['rgb'].shape == (2, H * W, 3)
+    for k in ('rgb', 'depth', 'opacity'):
+        assert_close(a[k], b[k].detach().cpu(), rtol=1e-6, atol=1e-7, name=k)
+    c, r = bg_nerf.get_center_and_ray(pose, H, W, intr)
+    c2, r2 = bg_nerf.get_center_and_ray_at_pixels(pose, torch.tensor([[0.5, 0.5], [W - 0.5, H - 0.5]]).cuda(), intr)
+    assert_close(r[:, [0, H * W - 1]], r2.cpu(), rtol=1e-6, atol=1e-7, name='corner rays')
