@@ -182,7 +182,7 @@ def _worker_scene(rank, world, port, q):
     opt = torch.optim.Adam([opt_p], lr=1e-3)
     opt_p.grad = mine / world                                   # == adam_flat(..., grad_scale = 1 / world)
     opt.step()
-    q.put((rank, opt_p.detach().clone(), torch.stack(grads).mean(0)))
+    q.put((rank, opt_p.detach().numpy().copy(), torch.stack(grads).mean(0).numpy().copy()))     # numpy: no shared-memory handles
     dist.barrier()
     dist.destroy_process_group()
 
@@ -198,9 +198,9 @@ def test_scene_gradient_all_reduce_keeps_replicas_identical():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert torch.equal(res[0][1], res[1][1])
+    assert (res[0][1] == res[1][1]).all()
     ref_p = torch.randn(1000, generator=torch.Generator().manual_seed(3)).requires_grad_(True)
     ref = torch.optim.Adam([ref_p], lr=1e-3)
-    ref_p.grad = res[0][2]
+    ref_p.grad = torch.tensor(res[0][2])
     ref.step()
-    assert torch.allclose(res[0][1], ref_p.detach(), rtol=0, atol=1e-7)
+    assert torch.allclose(torch.tensor(res[0][1]), ref_p.detach(), rtol=0, atol=1e-7)
