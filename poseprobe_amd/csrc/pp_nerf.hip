@@ -180,15 +180,17 @@ __global__ __launch_bounds__(256) void k_nerf_rgb_bwd(const float* __restrict__ 
 }
 
 // density head backward: column 256 of the last feature layer's output gradient carries d raw; wd / bd gradients.
-// Work-group = 4 wavefronts x 64 lanes; a lane owns 4 consecutive columns (float4 loads), a wavefront every 4th row of the
-// strip, so 4 rows are in flight per work-group and the 1 KB rows are read with 16-byte accesses.
-#define NERF_DSTRIP 512
-__global__ __launch_bounds__(256) void k_nerf_density_bwd(const float* __restrict__ a6, const float* __restrict__ raw,
-                                                          const float* __restrict__ g_density, int M,
-                                                          float* __restrict__ dY7, float* __restrict__ wdbar,
-                                                          float* __restrict__ bdbar) {
-  __shared__ float4 red[4][64];
-  __shared__ float redb[4];
+// Work-group = 16 wavefronts x 64 lanes over a strip of 1024 rows; a lane owns 4 consecutive columns (float4 loads), a
+// wavefront every 16th row, so 16 rows are in flight per work-group while only ONE set of 257 atomics per 1024 rows reaches
+// the (shared, hence serialised) gradient addresses - smaller strips are slower: 64 rows per work-group take 223 us, 512 with
+// four wavefronts 106 us at 131 k samples.
+#define NERF_DSTRIP 1024
+__global__ __launch_bounds__(1024) void k_nerf_density_bwd(const float* __restrict__ a6, const float* __restrict__ raw,
+                                                           const float* __restrict__ g_density, int M,
+                                                           float* __restrict__ dY7, float* __restrict__ wdbar,
+                                                           float* __restrict__ bdbar) {
+  __shared__ float4 red[16][64];
+  __shared__ float redb[16];
   const int m0 = blockIdx.x * NERF_DSTRIP;
   if (m0 >= M) return;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void k_nerf_density_bwd(const float* __restric
   float bacc = 0.f;
   const int mend = min(m0 + NERF_DSTRIP, M);
 #pragma unroll 4
-  for (int m = m0 + wid; m < mend; m += 4) {
+  for (int m = m0 + wid; m < mend; m += 16) {
     const float g = g_density[m] * nerf_dsoftplus(raw[m]);
     const float4 x = *reinterpret_cast<const float4*>(a6 + (size_t)m * 256 + lane * 4);
     acc.x += g * x.x; acc.y += g * x.y; acc.z += g * x.z; acc.w += g * x.w;
@@ -207,12 +209,19 @@ __global__ __launch_bounds__(256) void k_nerf_density_bwd(const float* __restric
   if (lane == 0) redb[wid] = bacc;
   __syncthreads();
   if (wid == 0) {
-    const float4 a = red[0][lane], b = red[1][lane], c = red[2][lane], d = red[3][lane];
-    atomicAdd(&wdbar[lane * 4 + 0], a.x + b.x + c.x + d.x);
-    atomicAdd(&wdbar[lane * 4 + 1], a.y + b.y + c.y + d.y);
-    atomicAdd(&wdbar[lane * 4 + 2], a.z + b.z + c.z + d.z);
-    atomicAdd(&wdbar[lane * 4 + 3], a.w + b.w + c.w + d.w);
-    if (lane == 0) atomicAdd(&bdbar[0], redb[0] + redb[1] + redb[2] + redb[3]);
+    float4 s = red[0][lane];
+    float sb = redb[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) {
+      const float4 t = red[w][lane];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      sb += redb[w];
+    }
+    atomicAdd(&wdbar[lane * 4 + 0], s.x);
+    atomicAdd(&wdbar[lane * 4 + 1], s.y);
+    atomicAdd(&wdbar[lane * 4 + 2], s.z);
+    atomicAdd(&wdbar[lane * 4 + 3], s.w);
+    if (lane == 0) atomicAdd(&bdbar[0], sb);
   }
 }
 
@@ -582,7 +591,7 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
   nerf_gemm<EPI_PLAIN>(st, dHsum, 128, R0T + 256 * 128, 128, 128, 32, nullptr, nullptr, 0, dView, 32, count, R);
   // last feature layer: columns 0..255 through the colour head, column 256 from the density
   nerf_gemm<EPI_MASK>(st, dH, 128, R0T, 128, 128, 256, nullptr, A.a[7], 288, P, 288, count, M);
-  hipLaunchKernelGGL(k_nerf_density_bwd, dim3(pp_div_up(M, NERF_DSTRIP)), b, 0, st, A.a[6], A.raw, g_density_samples, M, P,
+  hipLaunchKernelGGL(k_nerf_density_bwd, dim3(pp_div_up(M, NERF_DSTRIP)), dim3(1024), 0, st, A.a[6], A.raw, g_density_samples, M, P,
                      params_grad + L.wd, params_grad + L.bd);
   nerf_gemm_tn(st, P, 288, 256, A.a[6], 256, 256, params_grad + L.w[7], params_grad + L.b[7], count, M);
   nerf_gemm<EPI_MASK>(st, P, 288, WT[7], 288, 288, 256, nullptr, A.a[6], 256, Q, 256, count, M);
