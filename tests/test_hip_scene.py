@@ -336,3 +336,49 @@ def test_scene_render_by_slices_equals_one_pass():
     c, r = bg_nerf.get_center_and_ray(pose, H, W, intr)
     c2, r2 = bg_nerf.get_center_and_ray_at_pixels(pose, torch.tensor([[0.5, 0.5], [W - 0.5, H - 0.5]]).cuda(), intr)
     assert_close(r[:, [0, H * W - 1]], r2.cpu(), rtol=1e-6, atol=1e-7, name='corner rays')
+
+
+@pytest.mark.parametrize('R,S', [(1, 2), (3, 512), (5, 65)])
+def test_scene_edge_shapes_match_oracle(R, S):
+    """Smallest ray / sample counts, the maximum S the compositing kernels accept (512) and S just above one wave chunk."""
+    from oracle import scene_nerf as SN
+    net, opt = _net(progress=0.7)
+    g = torch.Generator().manual_seed(S)
+    center, ray = torch.randn(R, 3, generator=g) * 0.2, torch.randn(R, 3, generator=g)
+    depth = ((torch.rand(R, S, generator=g) + torch.arange(S)) / S * 2.0 + 0.4)
+    ref = SN.render(_oracle_params(net), center, ray, depth, 0.7, tuple(opt.barf_c2f))
+    dd = depth.cuda()[None, :, :, None]
+    pred = net.composite(opt, ray.cuda()[None], net.forward_samples(opt, center.cuda()[None], ray.cuda()[None], dd), dd)
+    for k in ('rgb', 'depth', 'opacity', 'weights', 'all_cumulated'):
+        assert_close(pred[k].reshape(-1), ref[k].reshape(-1), rtol=5e-5, atol=5e-6, name=k)
+
+
+def test_scene_sample_count_above_the_kernel_limit_is_refused():
+    from poseprobe_amd._lib import PoseProbeError
+    net, opt = _net()
+    c, r = torch.zeros(1, 2, 3).cuda(), torch.ones(1, 2, 3).cuda()
+    d = torch.linspace(0.5, 2, 513).cuda().reshape(1, 1, 513, 1).repeat(1, 2, 1, 1)
+    with pytest.raises(PoseProbeError, match='bad sizes'):
+        net.composite(opt, r, net.forward_samples(opt, c, r, d), d)
+
+
+def test_scene_inverse_depth_and_empty_medium():
+    """`nerf.depth.param = 'inverse'` (default_config.py:111-112) yields 1 / (t + 1e-8) samples; a medium with (numerically)
+    tiny density sends (almost) all weight to the last, 1e10-long interval: opacity 1, colour ~ the last sample's, finite gradients."""
+    from poseprobe_amd import bg_nerf
+    net, opt = _net(progress=1.0)
+    opt.nerf.depth.param = 'inverse'
+    dep = bg_nerf.sample_depth(opt, 1, 4, 8, (1, 0), mode='eval', device='cuda')
+    assert_close(dep[0, 0, :, 0], 1.0 / ((np.arange(8) + 0.5) / 8 * (0 - 1) + 1 + 1e-8), rtol=1e-5, name='inverse depth')
+    with torch.no_grad():
+        net.mlp_feat[-1].weight[0].zero_()
+        net.mlp_feat[-1].bias[0] = -14.0                    # softplus(-14) ~ 8e-7: x 1e10 still saturates the last interval
+    c = torch.zeros(1, 4, 3).cuda().requires_grad_(True)
+    r = torch.tensor([[[0., 0., 1.]] * 4]).cuda().requires_grad_(True)
+    pred = net.composite(opt, r, net.forward_samples(opt, c, r, dep), dep)
+    w = pred['weights'][0, :, :, 0]
+    assert float(w[:, :-1].abs().max()) < 1e-4 and float((w[:, -1] - 1).abs().max()) < 1e-3
+    assert_close(pred['rgb'][0], pred['rgb_samples'][0, :, -1].detach().cpu(), rtol=0, atol=2e-3, name='colour of the last sample')
+    assert_close(pred['opacity'].reshape(-1), np.ones(4, np.float32), rtol=1e-6, name='opacity')
+    pred['rgb'].sum().backward()
+    assert torch.isfinite(c.grad).all() and torch.isfinite(r.grad).all()
