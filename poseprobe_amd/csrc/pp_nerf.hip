@@ -16,6 +16,7 @@
 // (encoding, density head, 128 -> 3 colour head, compositing, encoding backward) are bandwidth-bound streaming kernels.
 #include "pp_common.h"
 #include "pp_gemm.h"
+#include "pp_gemm_split.h"
 #include <stdlib.h>
 
 #define NERF_L3D 10
@@ -55,7 +56,10 @@ extern "C" int pp_nerf_layout(int64_t* offsets) {
 }
 
 // activations kept for the backward pass; rows = samples
-struct NerfActs { float* enc; float* a[8]; float* h; float* raw; };
+// mx: largest magnitudes of the GEMM operands for the split-precision path (pp_gemm_split.h); slots below
+struct NerfActs { float* enc; float* a[8]; float* h; float* raw; float* mx; };
+enum { MX_ENC = 0, MX_A0 = 1 /* .. MX_A0 + 7 */, MX_DH = 9, MX_P = 10, MX_DY6 = 11 /* dY6 .. dY0 = 11 .. 17 */, MX_DHSUM = 18,
+       MX_W0 = 32 /* .. 39 */, MX_R0 = 40, MX_SLOTS = 64 };
 static NerfActs nerf_acts(float* base, int64_t M) {
   NerfActs A;
   float* p = base;
@@ -63,9 +67,10 @@ static NerfActs nerf_acts(float* base, int64_t M) {
   for (int l = 0; l < 8; ++l) { A.a[l] = p; p += M * NERF_OUT_LD[l]; }
   A.h = p; p += M * 128;
   A.raw = p; p += M;
+  A.mx = p; p += MX_SLOTS;
   return A;
 }
-static int64_t nerf_acts_floats(int64_t M) { return M * (64 + 256 * 6 + 320 + 288 + 128 + 1); }
+static int64_t nerf_acts_floats(int64_t M) { return M * (64 + 256 * 6 + 320 + 288 + 128 + 1) + MX_SLOTS; }
 static const int64_t NERF_WT_FLOATS = 5 * 65536 + 320 * 256 + 256 * 288 + 64 * 256 + 288 * 128;
 static int64_t nerf_scratch_floats(int64_t M, int64_t R) { return M * (320 * 2 + 64 * 2) + R * (128 + 32) + NERF_WT_FLOATS; }
 
@@ -111,6 +116,36 @@ __global__ __launch_bounds__(256) void k_nerf_encode(const float* __restrict__ c
   }
 }
 
+// split-precision path: bound of the encoded points' magnitude, max(1, |center + ray * t|_inf) at the smallest and largest depth of every ray
+// (the sines / cosines and the view encoding are bounded by 1) -> operand-maximum slots of the three consumers
+__global__ __launch_bounds__(256) void k_nerf_enc_bound(const float* __restrict__ center, const float* __restrict__ ray,
+                                                        const float* __restrict__ depth, int R, int S, float* __restrict__ mx) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  float v = 1.f;
+  if (r < R) {
+    float t0 = depth[(size_t)r * S], t1 = t0;           // smallest / largest depth of the ray, whatever the sample order
+    for (int i = 1; i < S; ++i) { const float t = depth[(size_t)r * S + i]; t0 = fminf(t0, t); t1 = fmaxf(t1, t); }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float o = center[r * 3 + c], d = ray[r * 3 + c];
+      v = fmaxf(v, fmaxf(fabsf(o + d * t0), fabsf(o + d * t1)));
+    }
+  }
+  pp_record_max(mx + MX_ENC, v);
+  pp_record_max(mx + MX_A0 + 3, v);
+  pp_record_max(mx + MX_A0 + 7, 1.f);
+}
+
+// largest |w| of the nine GEMM weight matrices (blockIdx.x selects; the last feature layer includes its density row)
+struct NerfWmaxJobs { const float* src[9]; int n[9]; };
+__global__ __launch_bounds__(256) void k_nerf_wmax(NerfWmaxJobs J, float* __restrict__ mx) {
+  const int q = blockIdx.x;
+  const float* __restrict__ p = J.src[q];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < J.n[q]; i += 256) v = fmaxf(v, fabsf(p[i]));
+  pp_record_max(mx + MX_W0 + q, v);
+}
+
 // ------------------------------------------------------------------------------------------------ thin heads
 __device__ __forceinline__ float nerf_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float nerf_dsoftplus(float x) { return x > 20.f ? 1.f : pp_sigmoid(x); }
@@ -154,13 +189,13 @@ __global__ __launch_bounds__(256) void k_nerf_rgb_fwd(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_nerf_rgb_bwd(const float* __restrict__ R1, const float* __restrict__ h,
                                                       const float* __restrict__ rgb, const float* __restrict__ g_rgb, int M,
                                                       float* __restrict__ dH, float* __restrict__ R1bar,
-                                                      float* __restrict__ br1bar) {
+                                                      float* __restrict__ br1bar, float* __restrict__ mx_dh) {
   __shared__ float red[3 * 128 + 4];
   const int m0 = blockIdx.x * NERF_STRIP;
   if (m0 >= M) return;
   const int half = threadIdx.x >> 7, j = threadIdx.x & 127;
   const float w[3] = {R1[j], R1[128 + j], R1[256 + j]};
-  float wacc[3] = {0, 0, 0}, bacc = 0.f;
+  float wacc[3] = {0, 0, 0}, bacc = 0.f, hmax = 0.f;
   const int mend = min(m0 + NERF_STRIP, M);
   for (int m = m0 + half; m < mend; m += 2) {
     float gl[3];
@@ -170,8 +205,10 @@ __global__ __launch_bounds__(256) void k_nerf_rgb_bwd(const float* __restrict__ 
     wacc[0] += gl[0] * x; wacc[1] += gl[1] * x; wacc[2] += gl[2] * x;
     const float hb = gl[0] * w[0] + gl[1] * w[1] + gl[2] * w[2];
     dH[(size_t)m * 128 + j] = (x > 0.f) ? hb : 0.f;
+    hmax = fmaxf(hmax, fabsf(hb));
     if (j < 3) bacc += gl[j];
   }
+  if (mx_dh) pp_record_max(mx_dh, hmax);
   if (half == 1) { for (int o = 0; o < 3; ++o) red[o * 128 + j] = wacc[o]; }
   if (half == 1 && j < 3) red[384 + j] = bacc;
   __syncthreads();
@@ -188,14 +225,14 @@ __global__ __launch_bounds__(256) void k_nerf_rgb_bwd(const float* __restrict__ 
 __global__ __launch_bounds__(1024) void k_nerf_density_bwd(const float* __restrict__ a6, const float* __restrict__ raw,
                                                            const float* __restrict__ g_density, int M,
                                                            float* __restrict__ dY7, float* __restrict__ wdbar,
-                                                           float* __restrict__ bdbar) {
+                                                           float* __restrict__ bdbar, float* __restrict__ mx_p) {
   __shared__ float4 red[16][64];
   __shared__ float redb[16];
   const int m0 = blockIdx.x * NERF_DSTRIP;
   if (m0 >= M) return;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float bacc = 0.f;
+  float bacc = 0.f, gmax = 0.f;
   const int mend = min(m0 + NERF_DSTRIP, M);
 #pragma unroll 4
   for (int m = m0 + wid; m < mend; m += 16) {
@@ -204,7 +241,9 @@ __global__ __launch_bounds__(1024) void k_nerf_density_bwd(const float* __restri
     acc.x += g * x.x; acc.y += g * x.y; acc.z += g * x.z; acc.w += g * x.w;
     if (lane < 32) dY7[(size_t)m * 288 + 256 + lane] = (lane == 0) ? g : 0.f;
     bacc += g;
+    gmax = fmaxf(gmax, fabsf(g));
   }
+  if (mx_p) pp_record_max(mx_p, gmax);
   red[wid][lane] = acc;
   if (lane == 0) redb[wid] = bacc;
   __syncthreads();
@@ -256,13 +295,15 @@ __global__ void k_nerf_wd_column(const float* __restrict__ wd, float* __restrict
 }
 
 // dHsum[r][j] = sum over the S samples of ray r of dH[m][j]
-__global__ __launch_bounds__(128) void k_nerf_ray_sum(const float* __restrict__ dH, int R, int S, float* __restrict__ out) {
+__global__ __launch_bounds__(128) void k_nerf_ray_sum(const float* __restrict__ dH, int R, int S, float* __restrict__ out,
+                                                      float* __restrict__ mx_sum) {
   const int r = blockIdx.x, j = threadIdx.x;
   if (r >= R) return;
   float acc = 0.f;
   const float* p = dH + (size_t)r * S * 128 + j;
   for (int s = 0; s < S; ++s) acc += p[(size_t)s * 128];
   out[(size_t)r * 128 + j] = acc;
+  if (mx_sum) pp_record_max(mx_sum, fabsf(acc));
 }
 
 // ------------------------------------------------------------------------------------------------ compositing
@@ -487,11 +528,28 @@ static int nerf_wide_tiles() {
   return v;
 }
 
+// PP_NERF_SPLIT=1: the NT GEMMs (forward and data gradients) run as three fp16 products with fp32-level accuracy
+// (pp_gemm_split.h); the weight-gradient GEMMs stay on the fp32 matrix instructions.  Off by default.
+static const int NERF_SPLIT = env_int("PP_NERF_SPLIT", 0) == 1;
+
 template <int EPI>
 static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, int K, int Nout, const float* bias,
-                      const float* mask, int ldm, float* C, int ldc, const int32_t* count, int rows) {
+                      const float* mask, int ldm, float* C, int ldc, const int32_t* count, int rows,
+                      const float* a_max = nullptr, const float* w_max = nullptr, float* c_max = nullptr) {
   const int tiles = pp_div_up(rows, NERF_BM);
   dim3 b(256);
+  if (NERF_SPLIT && a_max && w_max) {
+    if (Nout <= 64) {
+      dim3 g(tiles < 2 * NERF_GEMM_WGS ? tiles : 2 * NERF_GEMM_WGS, 1);
+      hipLaunchKernelGGL((k_gemm128s<EPI, 64>), g, b, 0, st, A, lda, W, ldw, K, Nout, bias, mask, ldm, C, ldc, count, rows, a_max,
+                         w_max, c_max);
+    } else {
+      dim3 g(tiles < NERF_GEMM_WGS ? tiles : NERF_GEMM_WGS, pp_div_up(Nout, 128));
+      hipLaunchKernelGGL((k_gemm128s<EPI, 128>), g, b, 0, st, A, lda, W, ldw, K, Nout, bias, mask, ldm, C, ldc, count, rows, a_max,
+                         w_max, c_max);
+    }
+    return;
+  }
   if (Nout == 256 && nerf_wide_tiles()) {    // 128 x 256 tile: the activation tile is read once, half the barriers per MFMA
     dim3 g(tiles < NERF_GEMM_WGS_WIDE ? tiles : NERF_GEMM_WGS_WIDE, 1);
     hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI, 1, NERF_BM, 256>), g, b, 0, st, A, lda, W, ldw, K, Nout, bias, mask, ldm, C,
@@ -528,17 +586,29 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
   const int M = n_rays * n_samples;
   const NerfLayout L = nerf_layout();
   NerfActs A = nerf_acts(acts, M);
+  float* mx = NERF_SPLIT ? A.mx : nullptr;
+  if (mx) {
+    hipMemsetAsync(mx, 0, MX_SLOTS * sizeof(float), st);
+    NerfWmaxJobs J;
+    for (int l = 0; l < 7; ++l) { J.src[l] = params + L.w[l]; J.n[l] = 256 * NERF_IN_LD[l]; }
+    J.src[7] = params + L.wd; J.n[7] = 257 * 256;
+    J.src[8] = params + L.r0; J.n[8] = 128 * 288;
+    hipLaunchKernelGGL(k_nerf_wmax, dim3(9), dim3(256), 0, st, J, mx);
+    hipLaunchKernelGGL(k_nerf_enc_bound, dim3(pp_div_up(n_rays, 256)), dim3(256), 0, st, center, ray, depth, n_rays, n_samples, mx);
+  }
   hipLaunchKernelGGL(k_nerf_encode, dim3(pp_div_up(M, 4)), dim3(256), 0, st, center, ray, depth, bands, M,
                      n_samples, A.enc, A.a[3], A.a[7]);
   const float* in = A.enc;
   for (int l = 0; l < 8; ++l) {
     nerf_gemm<EPI_RELU>(st, in, NERF_IN_LD[l], params + L.w[l], NERF_IN_LD[l], NERF_IN_LD[l], 256, params + L.b[l], nullptr, 0,
-                        A.a[l], NERF_OUT_LD[l], count, M);
+                        A.a[l], NERF_OUT_LD[l], count, M, mx ? mx + (l == 0 ? MX_ENC : MX_A0 + l - 1) : nullptr,
+                        mx ? mx + MX_W0 + l : nullptr, mx ? mx + MX_A0 + l : nullptr);
     in = A.a[l];
   }
   hipLaunchKernelGGL(k_nerf_density_fwd, dim3(pp_div_up(M, 4)), dim3(256), 0, st, A.a[6], params + L.wd, params + L.bd, M,
                      A.raw, density_samples);
-  nerf_gemm<EPI_RELU>(st, A.a[7], 288, params + L.r0, 288, 288, 128, params + L.br0, nullptr, 0, A.h, 128, count, M);
+  nerf_gemm<EPI_RELU>(st, A.a[7], 288, params + L.r0, 288, 288, 128, params + L.br0, nullptr, 0, A.h, 128, count, M,
+                      mx ? mx + MX_A0 + 7 : nullptr, mx ? mx + MX_R0 : nullptr, nullptr);
   hipLaunchKernelGGL(k_nerf_rgb_fwd, dim3(pp_div_up(M * 16, 256)), dim3(256), 0, st, params + L.r1, params + L.br1, A.h, M,
                      rgb_samples);
   PP_CHECK_LAUNCH();
@@ -582,32 +652,43 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
   }
   hipLaunchKernelGGL(k_nerf_wd_column, dim3(1), b, 0, st, params + L.wd, WT[7]);
 
+  // split-precision path: operand maxima of the gradient tensors are recorded by their producers (slots MX_DH .. MX_DHSUM)
+  float* mx = NERF_SPLIT ? A.mx : nullptr;
+  if (mx) hipMemsetAsync(mx + MX_DH, 0, (MX_DHSUM - MX_DH + 1) * sizeof(float), st);
+  auto slot = [&](int i) -> float* { return mx ? mx + i : nullptr; };
+
   // colour head
   float* dH = Q;                                   // [M][128]
   hipLaunchKernelGGL(k_nerf_rgb_bwd, dim3(pp_div_up(M, NERF_STRIP)), b, 0, st, params + L.r1, A.h, rgb_samples, g_rgb_samples,
-                     M, dH, params_grad + L.r1, params_grad + L.br1);
+                     M, dH, params_grad + L.r1, params_grad + L.br1, slot(MX_DH));
   nerf_gemm_tn(st, dH, 128, 128, A.a[7], 288, 288, params_grad + L.r0, params_grad + L.br0, count, M);
-  hipLaunchKernelGGL(k_nerf_ray_sum, dim3(R), dim3(128), 0, st, dH, R, S, dHsum);
-  nerf_gemm<EPI_PLAIN>(st, dHsum, 128, R0T + 256 * 128, 128, 128, 32, nullptr, nullptr, 0, dView, 32, count, R);
+  hipLaunchKernelGGL(k_nerf_ray_sum, dim3(R), dim3(128), 0, st, dH, R, S, dHsum, slot(MX_DHSUM));
+  nerf_gemm<EPI_PLAIN>(st, dHsum, 128, R0T + 256 * 128, 128, 128, 32, nullptr, nullptr, 0, dView, 32, count, R, slot(MX_DHSUM),
+                       slot(MX_R0), nullptr);
   // last feature layer: columns 0..255 through the colour head, column 256 from the density
-  nerf_gemm<EPI_MASK>(st, dH, 128, R0T, 128, 128, 256, nullptr, A.a[7], 288, P, 288, count, M);
+  nerf_gemm<EPI_MASK>(st, dH, 128, R0T, 128, 128, 256, nullptr, A.a[7], 288, P, 288, count, M, slot(MX_DH), slot(MX_R0),
+                      slot(MX_P));
   hipLaunchKernelGGL(k_nerf_density_bwd, dim3(pp_div_up(M, NERF_DSTRIP)), dim3(1024), 0, st, A.a[6], A.raw, g_density_samples, M, P,
-                     params_grad + L.wd, params_grad + L.bd);
+                     params_grad + L.wd, params_grad + L.bd, slot(MX_P));
   nerf_gemm_tn(st, P, 288, 256, A.a[6], 256, 256, params_grad + L.w[7], params_grad + L.b[7], count, M);
-  nerf_gemm<EPI_MASK>(st, P, 288, WT[7], 288, 288, 256, nullptr, A.a[6], 256, Q, 256, count, M);
+  nerf_gemm<EPI_MASK>(st, P, 288, WT[7], 288, 288, 256, nullptr, A.a[6], 256, Q, 256, count, M, slot(MX_P), slot(MX_W0 + 7),
+                      slot(MX_DY6));
   float* cur = Q;
   float* nxt = P;
   for (int l = 6; l >= 1; --l) {                   // cur = d(pre-activation of layer l), [M][256]
     const float* x = A.a[l - 1];
     const int ldx = NERF_OUT_LD[l - 1];            // 320 for layer 4's input (features + skip columns)
     nerf_gemm_tn(st, cur, 256, 256, x, ldx, NERF_IN_LD[l], params_grad + L.w[l], params_grad + L.b[l], count, M);
-    nerf_gemm<EPI_MASK>(st, cur, 256, WT[l], 256, 256, 256, nullptr, x, ldx, nxt, 256, count, M);
+    nerf_gemm<EPI_MASK>(st, cur, 256, WT[l], 256, 256, 256, nullptr, x, ldx, nxt, 256, count, M, slot(MX_DY6 + 6 - l),
+                        slot(MX_W0 + l), slot(MX_DY6 + 7 - l));
     if (l == 4)                                    // skip columns: gradient of the encoding, no activation in between
-      nerf_gemm<EPI_PLAIN>(st, cur, 256, WT[4] + 256 * 256, 256, 256, 64, nullptr, nullptr, 0, dEncS, 64, count, M);
+      nerf_gemm<EPI_PLAIN>(st, cur, 256, WT[4] + 256 * 256, 256, 256, 64, nullptr, nullptr, 0, dEncS, 64, count, M,
+                           slot(MX_DY6 + 2), slot(MX_W0 + 4), nullptr);
     float* t = cur; cur = nxt; nxt = t;
   }
   nerf_gemm_tn(st, cur, 256, 256, A.enc, 64, 64, params_grad + L.w[0], params_grad + L.b[0], count, M);
-  nerf_gemm<EPI_PLAIN>(st, cur, 256, WT[0], 256, 256, 64, nullptr, nullptr, 0, dEnc0, 64, count, M);
+  nerf_gemm<EPI_PLAIN>(st, cur, 256, WT[0], 256, 256, 64, nullptr, nullptr, 0, dEnc0, 64, count, M, slot(MX_DY6 + 6),
+                       slot(MX_W0), nullptr);
   hipLaunchKernelGGL(k_nerf_encode_bwd, dim3(R), b, 0, st, A.enc, dEnc0, dEncS, dView, A.a[7], ray, depth, R, S, g_center,
                      g_ray);
   PP_CHECK_LAUNCH();
