@@ -382,3 +382,18 @@ def test_scene_inverse_depth_and_empty_medium():
     assert_close(pred['opacity'].reshape(-1), np.ones(4, np.float32), rtol=1e-6, name='opacity')
     pred['rgb'].sum().backward()
     assert torch.isfinite(c.grad).all() and torch.isfinite(r.grad).all()
+
+
+def test_split_precision_mode_passes_the_reference_fixture():
+    """PP_NERF_SPLIT=1 (three fp16 products per fp32 product, csrc/pp_gemm_split.h) is read when the library is loaded, so the
+    reference-fixture test above is re-run in a child process with the switch on: same tolerances as the exact-fp32 path."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PP_NERF_SPLIT='1')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', 'tests/test_hip_scene.py', '-k',
+                        'matches_reference_outputs_and_backward or renderer_matches_reference_render or edge_shapes'],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
