@@ -7,8 +7,10 @@ link at W=2 and by a few links at W=8, so bytes on the wire are what matters).  
 
 mode "samples" (default) - exchange the k0 gradient at SAMPLE granularity
   * a rank's rays reach the dense 196 MB gradient grid through ~55 k samples only, so what travels is the INPUT of the
-    scatter: 64 B per sample (12 feature gradients + position), one all-gather of [capacity, 16] floats per rank
-    (12 MB) instead of a 196 MB reduce-scatter plus a 196 MB all-gather; it overlaps the geometry / warp backward,
+    scatter: 64 B per sample (12 feature gradients + position), one all-gather of [rows, 16] floats per rank instead of a
+    196 MB reduce-scatter plus a 196 MB all-gather; `rows` starts at the worst-case capacity (12 MB) and is cut to
+    1.5 x the largest sample count any rank has produced after two steps (5.4 MB at the bench workload; re-derived at
+    every resync); it overlaps the geometry / warp backward,
   * every rank replays the scatter for all shards (15 us each) and runs the full fused TV+Adam pass (replicated),
   * no parameter all-gather.  Float atomics make the replicas differ in the last bit, so every `resync_every` steps
     rank 0 broadcasts grid + moments (amortised to ~20 us / step).
@@ -35,7 +37,7 @@ def slab_bounds(X, world, rank):
 
 
 class DistContext:
-    def __init__(self, group=None, mode=None, resync_every=256):
+    def __init__(self, group=None, mode=None, resync_every=256, calib_steps=2, xcap_margin=1.5):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -46,6 +48,13 @@ class DistContext:
         self.resync_every = resync_every
         self._gathered = None
         self._steps = 0
+        # mode "samples": rows of the packed buffer that travel.  The compacted sample list fills only part of its
+        # worst-case capacity (29 % at the bench workload), so after `calib_steps` steps the exchange is cut to
+        # `xcap_margin` x the largest count any rank has seen (one host read + one MAX all-reduce, again at every resync).
+        self.calib_steps, self.xcap_margin = calib_steps, xcap_margin
+        self.xcap = None                   # None: full capacity
+        self._max_count = None
+        self.overflows = 0                 # windows in which some rank produced more samples than were exchanged
 
     # ---- generic tensor-level collectives (also exercised on CPU with gloo) ---------------------------------
     def shardable(self, X):
@@ -138,11 +147,15 @@ class DistContext:
         if self.mode == 'samples':
             from . import ops
             ws = eng.ws
+            xcap = self.xcap or ws.cap
             if getattr(ws, 'k0_packed', None) is None:
                 ws.k0_packed = torch.zeros(ws.cap, 16, dtype=torch.float32, device=ws.pts.device)
-                self._gathered = torch.zeros(self.world, ws.cap, 16, dtype=torch.float32, device=ws.pts.device)
-            ops.k0_pack_samples(ws.pts, ws.g_feat, ws.count, ws.cap, eng.cfg.k0_dim, ws.k0_packed)
-            _, self._grid_work = self.all_gather_rows(ws.k0_packed, self._gathered, async_op=True)
+                self._max_count = torch.zeros(1, dtype=torch.int32, device=ws.pts.device)
+            if self._gathered is None or self._gathered.shape[1] != xcap:
+                self._gathered = torch.zeros(self.world, xcap, 16, dtype=torch.float32, device=ws.pts.device)
+            torch.maximum(self._max_count, ws.count, out=self._max_count)
+            ops.k0_pack_samples(ws.pts, ws.g_feat, ws.count, xcap, eng.cfg.k0_dim, ws.k0_packed)   # rows past xcap are dropped
+            _, self._grid_work = self.all_gather_rows(ws.k0_packed[:xcap], self._gathered, async_op=True)
             return
         X = eng.k0_grad.shape[0]
         if self.shardable(X) and self.backend != 'gloo':
@@ -158,7 +171,7 @@ class DistContext:
             from . import ops
             self._grid_work.wait()
             self._grid_work = None
-            ops.k0_scatter_packed(eng.cfg.pp, self._gathered, self.world, eng.ws.cap, eng.k0_grad,
+            ops.k0_scatter_packed(eng.cfg.pp, self._gathered, self.world, self._gathered.shape[1], eng.k0_grad,
                                   eng.k0_touched[eng.touch_par])
             eng.x_slab = (0, X)
             self.all_reduce_small([eng.flat.grad, eng.se3_grad], async_op=True)     # finished by wait_small() after the grid pass
@@ -188,8 +201,11 @@ class DistContext:
         self._param_work = None
         if self.mode == 'samples':
             self._steps += 1
-            if self.resync_every and self._steps % self.resync_every == 0:
+            resync = self.resync_every and self._steps % self.resync_every == 0
+            if resync:
                 self.broadcast_state([eng.k0_cl, eng.k0_m, eng.k0_v])    # replicas differ in the last bit (float atomics)
+            if self._steps == self.calib_steps or resync:
+                self.calibrate_exchange(eng.ws.cap)
             return
         if self.shardable(X):
             if self.backend == 'gloo':
@@ -198,6 +214,26 @@ class DistContext:
                 xb, xe = slab_bounds(X, self.world, self.rank)
                 self._param_work = dist.all_gather_into_tensor(eng.k0_cl, eng.k0_cl[xb:xe], group=self.group,
                                                                async_op=True)
+
+    def exchange_rows(self, max_count, cap):
+        """Rows to exchange for a largest observed count: margin, 1024-row granularity, never above the capacity."""
+        return int(min(cap, -(-int(max_count * self.xcap_margin + 1024) // 1024) * 1024))
+
+    def calibrate_exchange(self, cap):
+        """(Re)size the sample exchange from the largest count any rank produced since the last call (the only host
+        synchronisation of the mode; every rank computes the same value).  A window whose count exceeded what travelled had
+        the tail of that rank's samples dropped on EVERY rank alike - replicas stay identical - and is counted in `overflows`."""
+        if self._max_count is None:
+            return
+        mx = self._max_count.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        m = int(mx.item())
+        if self.xcap is not None and m > self.xcap:
+            self.overflows += 1
+        self.xcap = max(self.exchange_rows(m, cap), 1024) if m > 0 else None
+        if self.xcap is not None and self.xcap >= cap:
+            self.xcap = None
+        self._max_count.zero_()
 
     def wait_parameters(self, eng):
         work = getattr(self, '_param_work', None)

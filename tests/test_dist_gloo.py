@@ -136,6 +136,17 @@ def _worker_samples(rank, world, port, q):
     tot = sum(range(1, world + 1))
     ok = ok and bool((a == tot).all()) and bool((b == 10.0 * tot).all())
     ctx.wait_small()                                             # idempotent
+    # adaptive exchange size: every rank derives the same row count from the largest sample count any rank has seen
+    ctx._max_count = torch.tensor([3000 + 900 * rank], dtype=torch.int32)
+    ctx.calibrate_exchange(cap=16384)
+    ok = ok and ctx.xcap == ctx.exchange_rows(3000 + 900 * (world - 1), 16384) == 7168 and ctx.overflows == 0
+    ok = ok and int(ctx._max_count) == 0
+    ctx._max_count = torch.tensor([9000 if rank == world - 1 else 100], dtype=torch.int32)      # one rank outgrew the exchange
+    ctx.calibrate_exchange(cap=16384)
+    ok = ok and ctx.overflows == 1 and ctx.xcap == 15360
+    ctx._max_count = torch.tensor([16000], dtype=torch.int32)
+    ctx.calibrate_exchange(cap=16384)
+    ok = ok and ctx.xcap is None                                 # back to the full capacity
     if rank == 0:
         q.put(bool(ok))
     dist.destroy_process_group()
