@@ -53,6 +53,43 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TNW], int r0, in
   }
 }
 
+// Epilogue with the ReLU mask kept as ONE BIT per activation: bits[row * 8 + column / 32] (outputs up to 256 columns wide).
+// EPI_RELU writes the words (wave ballot: lanes 0-31 are the 32 columns of a group for the row of the lower half-wave, lanes
+// 32-63 those of the row four below), EPI_MASK reads one word per row and column group instead of 32 scattered floats of the
+// forward activation: the backward epilogue's extra traffic drops from 4 bytes to 1 bit per element.  `cg0` = index of the
+// work-group's first 32-column group.  No lane leaves before the ballots (partial tiles are handled by predicates).
+template <int EPI, int TM, int TNW>
+__device__ __forceinline__ void gemm_epilogue_bits(f32x16 (&acc)[TM][TNW], int r0, int R, int Nout, int wr, int wc, int l31,
+                                                   int lh, const float* __restrict__ bias, uint32_t* __restrict__ bits,
+                                                   int cg0, float* __restrict__ C, int ldc) {
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+#pragma unroll
+    for (int u = 0; u < TNW; ++u) {
+      const int col = wc * (32 * TNW) + u * 32 + l31;
+      const bool col_ok = col < Nout;
+      const int cg = cg0 + wc * TNW + u;
+      const float bcol = (EPI == EPI_RELU && bias && col_ok) ? bias[col] : 0.f;
+      const int rbase = r0 + wr * (32 * TM) + t * 32 + 4 * lh;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = rbase + (reg & 3) + 8 * (reg >> 2);
+        const bool ok = col_ok && row < R;
+        float val = acc[t][u][reg];
+        if (EPI == EPI_RELU) {
+          val = fmaxf(val + bcol, 0.f);
+          const unsigned long long bal = __ballot(ok && val > 0.f);
+          if (l31 == 0 && row < R) bits[(size_t)row * 8 + cg] = (uint32_t)(lh ? (bal >> 32) : bal);
+        } else {
+          const uint32_t word = (row < R) ? bits[(size_t)row * 8 + cg] : 0u;
+          val = ((word >> l31) & 1u) ? val : 0.f;
+        }
+        if (ok) C[(size_t)row * ldc + col] = val;
+      }
+    }
+  }
+}
+
 // C[r][n] = epi( sum_k A[r][k] * B(n,k) ),  NT: B(n,k) = W[n*ldw + k]   NN: B(n,k) = W[k*ldw + n]
 // Register budget: the 128-column tile is left to the compiler (it takes 190-280 registers, 1-2 wavefronts per SIMD; capping
 // it at 168 for three work-groups per CU measured 10 % slower); the 256-column tile is capped at 256.
@@ -60,7 +97,8 @@ template <int MODE, int EPI, int COLS, int BM, int BN = 128>
 __global__ __launch_bounds__(256, ((BN == 256 || (EPI == EPI_MASK && BM == 128)) ? 2 : 1)) void k_gemm128(const float* __restrict__ A, int lda, const float* __restrict__ W_,
                                                  int ldw, int K, int Nout_, const float* __restrict__ bias_,
                                                  const float* __restrict__ Xmask_, int ldm, float* __restrict__ C_,
-                                                 int ldc, const int32_t* __restrict__ count, int rmul, int rcap) {
+                                                 int ldc, const int32_t* __restrict__ count, int rmul, int rcap,
+                                                 uint32_t* __restrict__ bits = nullptr) {
   constexpr int TM = BM / 64;            // 32-row MFMA tiles per wavefront (waves are arranged 2 x 2)
   constexpr int NA = BM / 32;            // float4 of the A tile per thread and K-chunk
   constexpr int TNW = BN / 64;           // 32-column MFMA tiles per wavefront
@@ -153,7 +191,9 @@ __global__ __launch_bounds__(256, ((BN == 256 || (EPI == EPI_MASK && BM == 128))
       __syncthreads();
     }
     // epilogue.  Full tiles (all but the last one) take a branch-free instantiation.
-    if ((r0 + BM <= R) && (Nout == BN))
+    if (COLS == 1 && EPI != EPI_PLAIN && bits)
+      gemm_epilogue_bits<EPI, TM, TNW>(acc, r0, R, Nout, wr, wc, l31, lh, bias, bits, cb / 32, C, ldc);
+    else if ((r0 + BM <= R) && (Nout == BN))
       gemm_epilogue<EPI, COLS, true, TM, TNW>(acc, r0, R, Nout, wr, wc, l31, lh, bias, Xmask, ldm, C, ldc);
     else
       gemm_epilogue<EPI, COLS, false, TM, TNW>(acc, r0, R, Nout, wr, wc, l31, lh, bias, Xmask, ldm, C, ldc);

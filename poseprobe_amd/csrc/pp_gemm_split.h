@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, PP_SPLIT_WAVES) void k_gemm128s(const float* _
                                                   const float* __restrict__ Xmask_, int ldm, float* __restrict__ C_, int ldc,
                                                   const int32_t* __restrict__ count, int rcap,
                                                   const float* __restrict__ a_max, const float* __restrict__ w_max,
-                                                  float* __restrict__ c_max) {
+                                                  float* __restrict__ c_max, uint32_t* __restrict__ bits = nullptr) {
   constexpr int BM = 128, TM = 2, NA = 4;
   constexpr int TNW = BN / 64, NB = BN / 32;
   __shared__ _Float16 Ah[BM * LDH], Al[BM * LDH], Bh[BN * LDH], Bl[BN * LDH];
@@ -156,11 +156,31 @@ __global__ __launch_bounds__(256, PP_SPLIT_WAVES) void k_gemm128s(const float* _
           if (row >= R) continue;
           float val = acc[t][u][reg] * inv;
           if (EPI == EPI_RELU) val = fmaxf(val + bcol, 0.f);
-          else if (EPI == EPI_MASK) val = (Xmask[(size_t)row * ldm + col] > 0.f) ? val : 0.f;
+          else if (EPI == EPI_MASK) {
+            const bool on = bits ? ((bits[(size_t)row * 8 + cb / 32 + wc * TNW + u] >> l31) & 1u) != 0u
+                                 : Xmask[(size_t)row * ldm + col] > 0.f;
+            val = on ? val : 0.f;
+          }
           C[(size_t)row * ldc + col] = val;
           vmax = fmaxf(vmax, fabsf(val));
         }
       }
+    if (EPI == EPI_RELU && bits) {        // one-bit ReLU masks for the exact-fp32 data-gradient kernels of a mixed run
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TNW; ++u) {
+          const int col = wc * (32 * TNW) + u * 32 + l31;
+          const float bcol = (bias && col < Nout) ? bias[col] : 0.f;
+          const int rbase = r0 + wr * 64 + t * 32 + 4 * lh;
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int row = rbase + (reg & 3) + 8 * (reg >> 2);
+            const unsigned long long bal = __ballot(col < Nout && row < R && acc[t][u][reg] * inv + bcol > 0.f);
+            if (l31 == 0 && row < R) bits[(size_t)row * 8 + cb / 32 + wc * TNW + u] = (uint32_t)(lh ? (bal >> 32) : bal);
+          }
+        }
+    }
   }
   pp_record_max(c_max, vmax);
 }

@@ -57,7 +57,8 @@ extern "C" int pp_nerf_layout(int64_t* offsets) {
 
 // activations kept for the backward pass; rows = samples
 // mx: largest magnitudes of the GEMM operands for the split-precision path (pp_gemm_split.h); slots below
-struct NerfActs { float* enc; float* a[8]; float* h; float* raw; float* mx; };
+// bits[l]: ReLU mask of layer l's output, one bit per activation, [M][8] words (pp_gemm.h gemm_epilogue_bits)
+struct NerfActs { float* enc; float* a[8]; float* h; float* raw; float* mx; uint32_t* bits[8]; };
 enum { MX_ENC = 0, MX_A0 = 1 /* .. MX_A0 + 7 */, MX_DH = 9, MX_P = 10, MX_DY6 = 11 /* dY6 .. dY0 = 11 .. 17 */, MX_DHSUM = 18,
        MX_W0 = 32 /* .. 39 */, MX_R0 = 40, MX_SLOTS = 64 };
 static NerfActs nerf_acts(float* base, int64_t M) {
@@ -68,9 +69,10 @@ static NerfActs nerf_acts(float* base, int64_t M) {
   A.h = p; p += M * 128;
   A.raw = p; p += M;
   A.mx = p; p += MX_SLOTS;
+  for (int l = 0; l < 8; ++l) { A.bits[l] = reinterpret_cast<uint32_t*>(p); p += M * 8; }
   return A;
 }
-static int64_t nerf_acts_floats(int64_t M) { return M * (64 + 256 * 6 + 320 + 288 + 128 + 1) + MX_SLOTS; }
+static int64_t nerf_acts_floats(int64_t M) { return M * (64 + 256 * 6 + 320 + 288 + 128 + 1 + 64) + MX_SLOTS; }
 static const int64_t NERF_WT_FLOATS = 5 * 65536 + 320 * 256 + 256 * 288 + 64 * 256 + 288 * 128;
 static int64_t nerf_scratch_floats(int64_t M, int64_t R) { return M * (320 * 2 + 64 * 2) + R * (128 + 32) + NERF_WT_FLOATS; }
 
@@ -531,13 +533,19 @@ static int nerf_wide_tiles() {
 // PP_NERF_SPLIT=1: the NT GEMMs (forward and data gradients) run as three fp16 products with fp32-level accuracy
 // (pp_gemm_split.h); the weight-gradient GEMMs stay on the fp32 matrix instructions.  Off by default.
 static const int NERF_SPLIT = env_int("PP_NERF_SPLIT", 0) == 1;
+// One-bit ReLU masks (pp_gemm.h gemm_epilogue_bits): on with the split-precision path, where the epilogues are what the
+// kernel waits for (4.59 -> 4.33 ms per scene step); off with the exact-fp32 path, whose branch-free full-tile epilogue is
+// faster than the ballots (4.54 vs 5.03 ms).  PP_NERF_BITMASK=1 / 2 forces them on / off.
+static const int NERF_BITMASK = env_int("PP_NERF_BITMASK", NERF_SPLIT ? 1 : 2) == 1;
 
 template <int EPI>
 static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, int K, int Nout, const float* bias,
                       const float* mask, int ldm, float* C, int ldc, const int32_t* count, int rows,
-                      const float* a_max = nullptr, const float* w_max = nullptr, float* c_max = nullptr) {
+                      const float* a_max = nullptr, const float* w_max = nullptr, float* c_max = nullptr,
+                      uint32_t* bits = nullptr) {
   const int tiles = pp_div_up(rows, NERF_BM);
   dim3 b(256);
+  if (!NERF_BITMASK) bits = nullptr;
   if (NERF_SPLIT && a_max && w_max) {
     if (Nout <= 64) {
       dim3 g(tiles < 2 * NERF_GEMM_WGS ? tiles : 2 * NERF_GEMM_WGS, 1);
@@ -546,7 +554,7 @@ static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, i
     } else {
       dim3 g(tiles < NERF_GEMM_WGS ? tiles : NERF_GEMM_WGS, pp_div_up(Nout, 128));
       hipLaunchKernelGGL((k_gemm128s<EPI, 128>), g, b, 0, st, A, lda, W, ldw, K, Nout, bias, mask, ldm, C, ldc, count, rows, a_max,
-                         w_max, c_max);
+                         w_max, c_max, bits);
     }
     return;
   }
@@ -564,7 +572,7 @@ static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, i
   }
   dim3 g(tiles < NERF_GEMM_WGS ? tiles : NERF_GEMM_WGS, pp_div_up(Nout, 128));
   hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI, 1, NERF_BM>), g, b, 0, st, A, lda, W, ldw, K, Nout, bias, mask, ldm, C, ldc,
-                     count, 1, rows);
+                     count, 1, rows, bits);
 }
 
 static void nerf_gemm_tn(hipStream_t st, const float* Y, int ldy, int N, const float* X, int ldx, int Kx, float* Wbar,
@@ -602,7 +610,7 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
   for (int l = 0; l < 8; ++l) {
     nerf_gemm<EPI_RELU>(st, in, NERF_IN_LD[l], params + L.w[l], NERF_IN_LD[l], NERF_IN_LD[l], 256, params + L.b[l], nullptr, 0,
                         A.a[l], NERF_OUT_LD[l], count, M, mx ? mx + (l == 0 ? MX_ENC : MX_A0 + l - 1) : nullptr,
-                        mx ? mx + MX_W0 + l : nullptr, mx ? mx + MX_A0 + l : nullptr);
+                        mx ? mx + MX_W0 + l : nullptr, mx ? mx + MX_A0 + l : nullptr, A.bits[l]);
     in = A.a[l];
   }
   hipLaunchKernelGGL(k_nerf_density_fwd, dim3(pp_div_up(M, 4)), dim3(256), 0, st, A.a[6], params + L.wd, params + L.bd, M,
@@ -667,12 +675,12 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
                        slot(MX_R0), nullptr);
   // last feature layer: columns 0..255 through the colour head, column 256 from the density
   nerf_gemm<EPI_MASK>(st, dH, 128, R0T, 128, 128, 256, nullptr, A.a[7], 288, P, 288, count, M, slot(MX_DH), slot(MX_R0),
-                      slot(MX_P));
+                      slot(MX_P), A.bits[7]);
   hipLaunchKernelGGL(k_nerf_density_bwd, dim3(pp_div_up(M, NERF_DSTRIP)), dim3(1024), 0, st, A.a[6], A.raw, g_density_samples, M, P,
                      params_grad + L.wd, params_grad + L.bd, slot(MX_P));
   nerf_gemm_tn(st, P, 288, 256, A.a[6], 256, 256, params_grad + L.w[7], params_grad + L.b[7], count, M);
   nerf_gemm<EPI_MASK>(st, P, 288, WT[7], 288, 288, 256, nullptr, A.a[6], 256, Q, 256, count, M, slot(MX_P), slot(MX_W0 + 7),
-                      slot(MX_DY6));
+                      slot(MX_DY6), A.bits[6]);
   float* cur = Q;
   float* nxt = P;
   for (int l = 6; l >= 1; --l) {                   // cur = d(pre-activation of layer l), [M][256]
@@ -680,7 +688,7 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
     const int ldx = NERF_OUT_LD[l - 1];            // 320 for layer 4's input (features + skip columns)
     nerf_gemm_tn(st, cur, 256, 256, x, ldx, NERF_IN_LD[l], params_grad + L.w[l], params_grad + L.b[l], count, M);
     nerf_gemm<EPI_MASK>(st, cur, 256, WT[l], 256, 256, 256, nullptr, x, ldx, nxt, 256, count, M, slot(MX_DY6 + 6 - l),
-                        slot(MX_W0 + l), slot(MX_DY6 + 7 - l));
+                        slot(MX_W0 + l), slot(MX_DY6 + 7 - l), A.bits[l - 1]);
     if (l == 4)                                    // skip columns: gradient of the encoding, no activation in between
       nerf_gemm<EPI_PLAIN>(st, cur, 256, WT[4] + 256 * 256, 256, 256, 64, nullptr, nullptr, 0, dEncS, 64, count, M,
                            slot(MX_DY6 + 2), slot(MX_W0 + 4), nullptr);
