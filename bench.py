@@ -135,7 +135,9 @@ def dual_branch_leg(eng, idx_all, jit_all, gs, N, V, H, W, object_ms, dev, steps
     fl_sample = 2 * (64 * 256 + 6 * 256 * 256 + 320 * 256 + 256 + 288 * 128 + 128 * 3)       # forward FLOP per sample
     out = {'workload': f'object-branch step + scene branch: {V} x {n_pix} rays, 8x256 NeRF (BARF PE), 2*huber loss, backward, '
                        f'Adam; shared poses, loss = 0.1 L_obj + L_bg; coarse phase = {S} stratified samples, hierarchical '
-                       f'phase = coarse + fine network on {S}+{S} samples', 'object_rays': N, 'scene_rays': V * n_pix, 'n_gpus': 1}
+                       f'phase = coarse + fine network on {S}+{S} samples', 'object_rays': N, 'scene_rays': V * n_pix, 'n_gpus': 1,
+           'scene_arithmetic': 'fp32 operands and accumulation; forward / data-gradient products as 3 fp16 MFMA products (error vs '
+                               'fp64 equal to the fp32 MFMA path), weight-gradient products on fp32 MFMA; PP_NERF_SPLIT=0: fp32 MFMA only'}
     for label, fine, samples in (('coarse_phase', False, V * n_pix * S), ('hierarchical_phase', True, V * n_pix * 3 * S)):
         for s in range(warmup):
             joint.train_step(idx_all[s % n_avail], jit_all[s % n_avail], gs + s, px[s], img, fine=fine)

@@ -10,10 +10,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum { MODE_NT = 0 };
 enum { EPI_RELU = 0, EPI_MASK = 1, EPI_PLAIN = 2 };
 
-template <int EPI, int COLS, bool FULL, int TM, int TNW = 2>
+// bits16 (optional, COLS == 1, outputs 256 columns wide): the ReLU mask as ONE BIT per activation.  A lane's 16 accumulator
+// registers of one 32 x 32 tile are 16 rows of ONE column, so it packs them into a 16-bit word without any cross-lane work:
+//   bits16[(row_group32 * 256 + column) * 2 + half],  bit j <-> row_group32 * 32 + (j & 3) + 8 * (j >> 2) + 4 * half
+// (the MFMA accumulator layout, the same in every kernel that uses 32 x 32 tiles).  EPI_RELU writes the words, EPI_MASK reads
+// one 2-byte word per tile and lane instead of 16 floats of the forward activation.  `cb` = first column of the work-group.
+template <int EPI, int COLS, bool FULL, int TM, int TNW = 2, bool BITS = false>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TNW], int r0, int R, int Nout, int wr, int wc, int l31,
                                               int lh, const float* __restrict__ bias,
-                                              const float* __restrict__ Xmask, int ldm, float* __restrict__ C, int ldc) {
+                                              const float* __restrict__ Xmask, int ldm, float* __restrict__ C, int ldc,
+                                              uint16_t* __restrict__ bits16 = nullptr, int cb = 0) {
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
 #pragma unroll
@@ -22,6 +28,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TNW], int r0, in
       if (!FULL && col >= Nout) continue;
       const float bcol = (EPI == EPI_RELU && bias) ? bias[col] : 0.f;
       const int rbase = r0 + wr * (32 * TM) + t * 32 + 4 * lh;
+      const size_t bidx = (((size_t)(rbase - 4 * lh) >> 5) * 256 + cb + col) * 2 + lh;
+      unsigned mbits = 0u;
+      if (BITS && COLS == 1 && EPI == EPI_MASK) mbits = bits16[bidx];
       float mk[4] = {1.f, 1.f, 1.f, 1.f};
       if (EPI == EPI_MASK && COLS == 4) {
 #pragma unroll
@@ -38,6 +47,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TNW], int r0, in
         if (EPI == EPI_RELU) {
           if (COLS == 1) {
             val = fmaxf(val + bcol, 0.f);
+            if (BITS) mbits |= (val > 0.f ? 1u : 0u) << reg;
           } else {
             const float y0 = acc[t][u][reg & ~3] + bcol;   // primal row of this sample (same lane)
             const float y = val + (((reg & 3) == 0) ? bcol : 0.f);
@@ -45,47 +55,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TNW], int r0, in
           }
         } else if (EPI == EPI_MASK) {
           if (COLS == 4) val = (mk[reg >> 2] > 0.f) ? val : 0.f;
+          else if (BITS) val = ((mbits >> reg) & 1u) ? val : 0.f;
           else val = (Xmask[(size_t)row * ldm + col] > 0.f) ? val : 0.f;
         }
         C[(size_t)row * ldc + col] = val;
       }
-    }
-  }
-}
-
-// Epilogue with the ReLU mask kept as ONE BIT per activation: bits[row * 8 + column / 32] (outputs up to 256 columns wide).
-// EPI_RELU writes the words (wave ballot: lanes 0-31 are the 32 columns of a group for the row of the lower half-wave, lanes
-// 32-63 those of the row four below), EPI_MASK reads one word per row and column group instead of 32 scattered floats of the
-// forward activation: the backward epilogue's extra traffic drops from 4 bytes to 1 bit per element.  `cg0` = index of the
-// work-group's first 32-column group.  No lane leaves before the ballots (partial tiles are handled by predicates).
-template <int EPI, int TM, int TNW>
-__device__ __forceinline__ void gemm_epilogue_bits(f32x16 (&acc)[TM][TNW], int r0, int R, int Nout, int wr, int wc, int l31,
-                                                   int lh, const float* __restrict__ bias, uint32_t* __restrict__ bits,
-                                                   int cg0, float* __restrict__ C, int ldc) {
-#pragma unroll
-  for (int t = 0; t < TM; ++t) {
-#pragma unroll
-    for (int u = 0; u < TNW; ++u) {
-      const int col = wc * (32 * TNW) + u * 32 + l31;
-      const bool col_ok = col < Nout;
-      const int cg = cg0 + wc * TNW + u;
-      const float bcol = (EPI == EPI_RELU && bias && col_ok) ? bias[col] : 0.f;
-      const int rbase = r0 + wr * (32 * TM) + t * 32 + 4 * lh;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = rbase + (reg & 3) + 8 * (reg >> 2);
-        const bool ok = col_ok && row < R;
-        float val = acc[t][u][reg];
-        if (EPI == EPI_RELU) {
-          val = fmaxf(val + bcol, 0.f);
-          const unsigned long long bal = __ballot(ok && val > 0.f);
-          if (l31 == 0 && row < R) bits[(size_t)row * 8 + cg] = (uint32_t)(lh ? (bal >> 32) : bal);
-        } else {
-          const uint32_t word = (row < R) ? bits[(size_t)row * 8 + cg] : 0u;
-          val = ((word >> l31) & 1u) ? val : 0.f;
-        }
-        if (ok) C[(size_t)row * ldc + col] = val;
-      }
+      if (BITS && COLS == 1 && EPI == EPI_RELU) bits16[bidx] = (uint16_t)mbits;
     }
   }
 }
@@ -93,12 +68,12 @@ __device__ __forceinline__ void gemm_epilogue_bits(f32x16 (&acc)[TM][TNW], int r
 // C[r][n] = epi( sum_k A[r][k] * B(n,k) ),  NT: B(n,k) = W[n*ldw + k]   NN: B(n,k) = W[k*ldw + n]
 // Register budget: the 128-column tile is left to the compiler (it takes 190-280 registers, 1-2 wavefronts per SIMD; capping
 // it at 168 for three work-groups per CU measured 10 % slower); the 256-column tile is capped at 256.
-template <int MODE, int EPI, int COLS, int BM, int BN = 128>
+template <int MODE, int EPI, int COLS, int BM, int BN = 128, bool BITS = false>
 __global__ __launch_bounds__(256, ((BN == 256 || (EPI == EPI_MASK && BM == 128)) ? 2 : 1)) void k_gemm128(const float* __restrict__ A, int lda, const float* __restrict__ W_,
                                                  int ldw, int K, int Nout_, const float* __restrict__ bias_,
                                                  const float* __restrict__ Xmask_, int ldm, float* __restrict__ C_,
                                                  int ldc, const int32_t* __restrict__ count, int rmul, int rcap,
-                                                 uint32_t* __restrict__ bits = nullptr) {
+                                                 uint16_t* __restrict__ bits16 = nullptr) {
   constexpr int TM = BM / 64;            // 32-row MFMA tiles per wavefront (waves are arranged 2 x 2)
   constexpr int NA = BM / 32;            // float4 of the A tile per thread and K-chunk
   constexpr int TNW = BN / 64;           // 32-column MFMA tiles per wavefront
@@ -191,12 +166,10 @@ __global__ __launch_bounds__(256, ((BN == 256 || (EPI == EPI_MASK && BM == 128))
       __syncthreads();
     }
     // epilogue.  Full tiles (all but the last one) take a branch-free instantiation.
-    if (COLS == 1 && EPI != EPI_PLAIN && bits)
-      gemm_epilogue_bits<EPI, TM, TNW>(acc, r0, R, Nout, wr, wc, l31, lh, bias, bits, cb / 32, C, ldc);
-    else if ((r0 + BM <= R) && (Nout == BN))
-      gemm_epilogue<EPI, COLS, true, TM, TNW>(acc, r0, R, Nout, wr, wc, l31, lh, bias, Xmask, ldm, C, ldc);
+    if ((r0 + BM <= R) && (Nout == BN))
+      gemm_epilogue<EPI, COLS, true, TM, TNW, BITS>(acc, r0, R, Nout, wr, wc, l31, lh, bias, Xmask, ldm, C, ldc, bits16, cb);
     else
-      gemm_epilogue<EPI, COLS, false, TM, TNW>(acc, r0, R, Nout, wr, wc, l31, lh, bias, Xmask, ldm, C, ldc);
+      gemm_epilogue<EPI, COLS, false, TM, TNW, BITS>(acc, r0, R, Nout, wr, wc, l31, lh, bias, Xmask, ldm, C, ldc, bits16, cb);
   }
 }
 

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, PP_SPLIT_WAVES) void k_gemm128s(const float* _
                                                   const float* __restrict__ Xmask_, int ldm, float* __restrict__ C_, int ldc,
                                                   const int32_t* __restrict__ count, int rcap,
                                                   const float* __restrict__ a_max, const float* __restrict__ w_max,
-                                                  float* __restrict__ c_max, uint32_t* __restrict__ bits = nullptr) {
+                                                  float* __restrict__ c_max, uint16_t* __restrict__ bits16 = nullptr) {
   constexpr int BM = 128, TM = 2, NA = 4;
   constexpr int TNW = BN / 64, NB = BN / 32;
   __shared__ _Float16 Ah[BM * LDH], Al[BM * LDH], Bh[BN * LDH], Bl[BN * LDH];
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256, PP_SPLIT_WAVES) void k_gemm128s(const float* _
       }
       __syncthreads();
     }
-    // epilogue: un-scale, bias + ReLU / ReLU mask / plain, record the largest magnitude written
+    // epilogue: un-scale, bias + ReLU / ReLU mask / plain, record the largest magnitude written; the ReLU mask travels as
+    // one bit per activation when `bits16` is given (layout: pp_gemm.h gemm_epilogue)
 #pragma unroll
     for (int t = 0; t < TM; ++t)
 #pragma unroll
@@ -150,37 +151,25 @@ __global__ __launch_bounds__(256, PP_SPLIT_WAVES) void k_gemm128s(const float* _
         if (col >= Nout) continue;
         const float bcol = (EPI == EPI_RELU && bias) ? bias[col] : 0.f;
         const int rbase = r0 + wr * 64 + t * 32 + 4 * lh;
+        const size_t bidx = (((size_t)(rbase - 4 * lh) >> 5) * 256 + cb + col) * 2 + lh;
+        unsigned mbits = (EPI == EPI_MASK && bits16) ? bits16[bidx] : 0u;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int row = rbase + (reg & 3) + 8 * (reg >> 2);
           if (row >= R) continue;
           float val = acc[t][u][reg] * inv;
-          if (EPI == EPI_RELU) val = fmaxf(val + bcol, 0.f);
-          else if (EPI == EPI_MASK) {
-            const bool on = bits ? ((bits[(size_t)row * 8 + cb / 32 + wc * TNW + u] >> l31) & 1u) != 0u
-                                 : Xmask[(size_t)row * ldm + col] > 0.f;
+          if (EPI == EPI_RELU) {
+            val = fmaxf(val + bcol, 0.f);
+            mbits |= (val > 0.f ? 1u : 0u) << reg;
+          } else if (EPI == EPI_MASK) {
+            const bool on = bits16 ? ((mbits >> reg) & 1u) != 0u : Xmask[(size_t)row * ldm + col] > 0.f;
             val = on ? val : 0.f;
           }
           C[(size_t)row * ldc + col] = val;
           vmax = fmaxf(vmax, fabsf(val));
         }
+        if (EPI == EPI_RELU && bits16) bits16[bidx] = (uint16_t)mbits;
       }
-    if (EPI == EPI_RELU && bits) {        // one-bit ReLU masks for the exact-fp32 data-gradient kernels of a mixed run
-#pragma unroll
-      for (int t = 0; t < TM; ++t)
-#pragma unroll
-        for (int u = 0; u < TNW; ++u) {
-          const int col = wc * (32 * TNW) + u * 32 + l31;
-          const float bcol = (bias && col < Nout) ? bias[col] : 0.f;
-          const int rbase = r0 + wr * 64 + t * 32 + 4 * lh;
-#pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const int row = rbase + (reg & 3) + 8 * (reg >> 2);
-            const unsigned long long bal = __ballot(col < Nout && row < R && acc[t][u][reg] * inv + bcol > 0.f);
-            if (l31 == 0 && row < R) bits[(size_t)row * 8 + cb / 32 + wc * TNW + u] = (uint32_t)(lh ? (bal >> 32) : bal);
-          }
-        }
-    }
   }
   pp_record_max(c_max, vmax);
 }

@@ -1,5 +1,6 @@
 // Scene branch (lib/bg_nerf): the 8 x 256 NeRF MLP with BARF positional encoding and exp-cumsum compositing, forward and
-// backward, exact fp32 on the CDNA4 matrix cores.
+// backward, fp32 in memory and fp32-accurate on the CDNA4 matrix cores (forward / data-gradient products as three fp16
+// products with fp32 accumulation, weight-gradient products on the fp32 instructions; PP_NERF_SPLIT=0: fp32 instructions only).
 //
 //   reference: lib/bg_nerf/source/models/frequency_nerf.py
 //     :42-69    FrequencyEmbedder          (sin / cos of 2^l * pi * x, layout [coordinate][sin|cos][band])
@@ -57,8 +58,8 @@ extern "C" int pp_nerf_layout(int64_t* offsets) {
 
 // activations kept for the backward pass; rows = samples
 // mx: largest magnitudes of the GEMM operands for the split-precision path (pp_gemm_split.h); slots below
-// bits[l]: ReLU mask of layer l's output, one bit per activation, [M][8] words (pp_gemm.h gemm_epilogue_bits)
-struct NerfActs { float* enc; float* a[8]; float* h; float* raw; float* mx; uint32_t* bits[8]; };
+// bits[l]: ReLU mask of layer l's output, one bit per activation, 32 bytes per sample (layout: pp_gemm.h gemm_epilogue)
+struct NerfActs { float* enc; float* a[8]; float* h; float* raw; float* mx; uint16_t* bits[8]; };
 enum { MX_ENC = 0, MX_A0 = 1 /* .. MX_A0 + 7 */, MX_DH = 9, MX_P = 10, MX_DY6 = 11 /* dY6 .. dY0 = 11 .. 17 */, MX_DHSUM = 18,
        MX_W0 = 32 /* .. 39 */, MX_R0 = 40, MX_SLOTS = 64 };
 static NerfActs nerf_acts(float* base, int64_t M) {
@@ -69,10 +70,10 @@ static NerfActs nerf_acts(float* base, int64_t M) {
   A.h = p; p += M * 128;
   A.raw = p; p += M;
   A.mx = p; p += MX_SLOTS;
-  for (int l = 0; l < 8; ++l) { A.bits[l] = reinterpret_cast<uint32_t*>(p); p += M * 8; }
+  for (int l = 0; l < 8; ++l) { A.bits[l] = reinterpret_cast<uint16_t*>(p); p += (M + 127) / 128 * 128 * 8; }
   return A;
 }
-static int64_t nerf_acts_floats(int64_t M) { return M * (64 + 256 * 6 + 320 + 288 + 128 + 1 + 64) + MX_SLOTS; }
+static int64_t nerf_acts_floats(int64_t M) { return M * (64 + 256 * 6 + 320 + 288 + 128 + 1) + MX_SLOTS + (M + 127) / 128 * 128 * 64; }
 static const int64_t NERF_WT_FLOATS = 5 * 65536 + 320 * 256 + 256 * 288 + 64 * 256 + 288 * 128;
 static int64_t nerf_scratch_floats(int64_t M, int64_t R) { return M * (320 * 2 + 64 * 2) + R * (128 + 32) + NERF_WT_FLOATS; }
 
@@ -516,6 +517,7 @@ __global__ __launch_bounds__(256) void k_nerf_encode_bwd(const float* __restrict
 // ------------------------------------------------------------------------------------------------ host side
 static const int NERF_BM = 128;
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && atoi(e) > 0) ? atoi(e) : dflt; }
+static bool env_flag(const char* name, bool dflt) { const char* e = getenv(name); return (e && e[0]) ? (e[0] == '1') : dflt; }
 static const int NERF_GEMM_WGS = env_int("PP_NERF_GEMM_WGS", 256);     // persistent work-groups per column block (measured: 256 = 512 > 384 > 128)
 static const int NERF_GEMM_WGS_WIDE = 512;   // 128 x 256 tiles: 2 resident per CU (55 KB LDS, ~220 registers)
 static const int NERF_TN_CH = env_int("PP_NERF_TN_CH", 64);           // rows per LDS chunk of the weight-gradient GEMM (32 | 64)
@@ -530,19 +532,20 @@ static int nerf_wide_tiles() {
   return v;
 }
 
-// PP_NERF_SPLIT=1: the NT GEMMs (forward and data gradients) run as three fp16 products with fp32-level accuracy
-// (pp_gemm_split.h); the weight-gradient GEMMs stay on the fp32 matrix instructions.  Off by default.
-static const int NERF_SPLIT = env_int("PP_NERF_SPLIT", 0) == 1;
-// One-bit ReLU masks (pp_gemm.h gemm_epilogue_bits): on with the split-precision path, where the epilogues are what the
-// kernel waits for (4.59 -> 4.33 ms per scene step); off with the exact-fp32 path, whose branch-free full-tile epilogue is
-// faster than the ballots (4.54 vs 5.03 ms).  PP_NERF_BITMASK=1 / 2 forces them on / off.
-static const int NERF_BITMASK = env_int("PP_NERF_BITMASK", NERF_SPLIT ? 1 : 2) == 1;
+// The NT GEMMs (forward and data gradients) run as three fp16 products with fp32 accumulation (pp_gemm_split.h: error
+// against fp64 equal to the fp32 matrix instructions', a third of their matrix-pipe time); the weight-gradient GEMMs use the
+// fp32 matrix instructions.  PP_NERF_SPLIT=0 puts the NT GEMMs on the fp32 instructions as well (A/B runs, bisecting).
+static const bool NERF_SPLIT = env_flag("PP_NERF_SPLIT", true);
+// One-bit ReLU masks (pp_gemm.h gemm_epilogue): the forward epilogue packs a lane's 16 rows of a column into a 16-bit word,
+// the data-gradient epilogue reads that word instead of 16 floats of the forward activation.  Neutral for the exact-fp32
+// path (12.1 vs 12.0 ms at 3072 x 128 samples), -11..-17 % with the split-precision path.  PP_NERF_BITMASK=0 switches them off.
+static const bool NERF_BITMASK = env_flag("PP_NERF_BITMASK", true);
 
 template <int EPI>
 static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, int K, int Nout, const float* bias,
                       const float* mask, int ldm, float* C, int ldc, const int32_t* count, int rows,
                       const float* a_max = nullptr, const float* w_max = nullptr, float* c_max = nullptr,
-                      uint32_t* bits = nullptr) {
+                      uint16_t* bits = nullptr) {
   const int tiles = pp_div_up(rows, NERF_BM);
   dim3 b(256);
   if (!NERF_BITMASK) bits = nullptr;
@@ -571,8 +574,12 @@ static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, i
     return;
   }
   dim3 g(tiles < NERF_GEMM_WGS ? tiles : NERF_GEMM_WGS, pp_div_up(Nout, 128));
-  hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI, 1, NERF_BM>), g, b, 0, st, A, lda, W, ldw, K, Nout, bias, mask, ldm, C, ldc,
-                     count, 1, rows, bits);
+  if (bits && EPI != EPI_PLAIN)
+    hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI, 1, NERF_BM, 128, true>), g, b, 0, st, A, lda, W, ldw, K, Nout, bias, mask, ldm, C,
+                       ldc, count, 1, rows, bits);
+  else
+    hipLaunchKernelGGL((k_gemm128<MODE_NT, EPI, 1, NERF_BM>), g, b, 0, st, A, lda, W, ldw, K, Nout, bias, mask, ldm, C, ldc,
+                       count, 1, rows);
 }
 
 static void nerf_gemm_tn(hipStream_t st, const float* Y, int ldy, int N, const float* X, int ldx, int Kx, float* Wbar,

@@ -384,13 +384,14 @@ def test_scene_inverse_depth_and_empty_medium():
     assert torch.isfinite(c.grad).all() and torch.isfinite(r.grad).all()
 
 
-def test_split_precision_mode_passes_the_reference_fixture():
-    """PP_NERF_SPLIT=1 (three fp16 products per fp32 product, csrc/pp_gemm_split.h) is read when the library is loaded, so the
-    reference-fixture test above is re-run in a child process with the switch on: same tolerances as the exact-fp32 path."""
+def test_fp32_instruction_mode_passes_the_reference_fixture():
+    """The default runs the forward / data-gradient products as three fp16 products (csrc/pp_gemm_split.h); PP_NERF_SPLIT=0
+    puts them on the fp32 matrix instructions.  The switch is read when the library is loaded, so the reference-fixture tests
+    are re-run in a child process with it: same tolerances in both modes."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, PP_NERF_SPLIT='1')
+    env = dict(os.environ, PP_NERF_SPLIT='0')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', 'tests/test_hip_scene.py', '-k',
                         'matches_reference_outputs_and_backward or renderer_matches_reference_render or edge_shapes'],
