@@ -173,3 +173,141 @@ __global__ __launch_bounds__(256, PP_SPLIT_WAVES) void k_gemm128s(const float* _
   }
   pp_record_max(c_max, vmax);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Split-precision weight gradient:  Wbar[n][k] += sum_r Y[r][n] X[r][k]  (one 128 x 128 block per blockIdx.y, row splits
+// along blockIdx.x, as k_gemm_tn), three fp16 products per fp32 product.  The reduction runs over ROWS, so an MFMA operand
+// fragment is 8 consecutive rows of one column: a thread therefore loads 8 consecutive rows x 4 columns of the chunk (512-byte
+// coalesced row segments), splits them and writes each column's 8 rows as ONE 16-byte value into a column-major LDS image
+// T[column][64 rows + 8] - the transpose costs nothing but the store pattern.  Column stride 144 B; the eight 16-byte row
+// blocks of a column are XOR-swizzled with (column / 4) & 7, which brings the stores (lanes 4 columns apart) to the 4 passes
+// a 16-byte store of 32 lanes needs anyway and leaves the fragment reads (ds_read_b128, consecutive columns) at most 2-way.
+// ------------------------------------------------------------------------------------------------------------------
+#define LDC 72        // halfs per LDS column: 64 rows + 8 (144 B)
+
+__global__ __launch_bounds__(256) void k_gemm_tn_split(const float* __restrict__ Y_, int ldy, const float* __restrict__ X_, int ldx,
+                                                       int Kx_, float* __restrict__ Wbar_, int ldwb, float* __restrict__ bbar_,
+                                                       const int32_t* __restrict__ count, int rcap,
+                                                       const float* __restrict__ y_max, const float* __restrict__ x_max) {
+  constexpr int CH = 64;
+  __shared__ _Float16 Yh[128 * LDC], Yl[128 * LDC], Xh[128 * LDC], Xl[128 * LDC];
+  const int nkb = (Kx_ + 127) >> 7;
+  const int nb = blockIdx.y / nkb, kb = blockIdx.y - nb * nkb;
+  const float* __restrict__ Y = Y_ + nb * 128;
+  const float* __restrict__ X = X_ + kb * 128;
+  const int Kx = min(128, Kx_ - kb * 128);
+  float* __restrict__ Wbar = Wbar_ + (size_t)nb * 128 * ldwb + kb * 128;
+  float* __restrict__ bbar = (bbar_ && kb == 0) ? bbar_ + nb * 128 : nullptr;
+  const int R = min(count[0], rcap);
+  const int rows_per_wg = ((R + (int)gridDim.x - 1) / (int)gridDim.x + CH - 1) / CH * CH;
+  const int rb = blockIdx.x * rows_per_wg;
+  if (rb >= R) return;
+  const int re = min(rb + rows_per_wg, R);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const float sY = pp_split_scale(y_max[0]), sX = pp_split_scale(x_max[0]);
+  const int c4 = tid & 31, rblk = tid >> 5;                 // this thread: columns 4 c4 .. 4 c4 + 3, rows 8 rblk .. 8 rblk + 7
+  const int kx4 = Kx >> 2;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 ry[8], rx[8];
+  auto load_rows = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int gr = r0 + rblk * 8 + i;
+      ry[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rx[i] = ry[i];
+      if (gr < re) {
+        ry[i] = *reinterpret_cast<const float4*>(Y + (size_t)gr * ldy + c4 * 4);
+        if (c4 < kx4) rx[i] = *reinterpret_cast<const float4*>(X + (size_t)gr * ldx + c4 * 4);
+      }
+    }
+  };
+  auto store_col = [&](const float4 (&r)[8], int j, float s, _Float16* Th, _Float16* Tl) {
+    pp_half8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float x = (j == 0 ? r[i].x : j == 1 ? r[i].y : j == 2 ? r[i].z : r[i].w) * s;
+      const _Float16 hh = (_Float16)x;
+      h[i] = hh;
+      l[i] = (_Float16)(x - (float)hh);
+    }
+    const int o = (c4 * 4 + j) * LDC + ((rblk ^ (c4 & 7)) * 8);
+    *reinterpret_cast<pp_half8*>(Th + o) = h;
+    *reinterpret_cast<pp_half8*>(Tl + o) = l;
+  };
+  load_rows(rb);
+  for (int r0 = rb; r0 < re; r0 += CH) {
+    store_col(ry, 0, sY, Yh, Yl); store_col(ry, 1, sY, Yh, Yl); store_col(ry, 2, sY, Yh, Yl); store_col(ry, 3, sY, Yh, Yl);
+    store_col(rx, 0, sX, Xh, Xl); store_col(rx, 1, sX, Xh, Xl); store_col(rx, 2, sX, Xh, Xl); store_col(rx, 3, sX, Xh, Xl);
+    if (bbar) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { bsum[0] += ry[i].x; bsum[1] += ry[i].y; bsum[2] += ry[i].z; bsum[3] += ry[i].w; }
+    }
+    __syncthreads();
+    if (r0 + CH < re) load_rows(r0 + CH);
+    if (wc * 64 < Kx) {
+#pragma unroll
+      for (int ks = 0; ks < CH; ks += 16) {
+        pp_half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int col = wr * 64 + t * 32 + l31;
+          const int o = col * LDC + ((((ks >> 3) + lh) ^ ((col >> 2) & 7)) * 8);
+          ah[t] = *reinterpret_cast<const pp_half8*>(Yh + o);
+          al[t] = *reinterpret_cast<const pp_half8*>(Yl + o);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int col = wc * 64 + u * 32 + l31;
+          const int o = col * LDC + ((((ks >> 3) + lh) ^ ((col >> 2) & 7)) * 8);
+          bh[u] = *reinterpret_cast<const pp_half8*>(Xh + o);
+          bl[u] = *reinterpret_cast<const pp_half8*>(Xl + o);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[u], acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[u], acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[u], acc[t][u], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+  const float inv = 1.0f / (sY * sX);
+  if (wc * 64 < Kx) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = wc * 64 + u * 32 + l31;
+        if (k >= Kx) continue;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int n = wr * 64 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+          atomicAdd(&Wbar[(size_t)n * ldwb + k], acc[t][u][reg] * inv);
+        }
+      }
+  }
+  if (bbar) {                              // 8 row blocks x 128 columns of partial sums -> one atomic per column
+    float* red = reinterpret_cast<float*>(Yh);            // the operand images are dead (last chunk ended with a barrier)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rblk * 128 + c4 * 4 + j] = bsum[j];
+    __syncthreads();
+    if (tid < 128) {
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sum += red[q * 128 + tid];
+      atomicAdd(&bbar[tid], sum);
+    }
+  }
+}

@@ -521,6 +521,7 @@ static bool env_flag(const char* name, bool dflt) { const char* e = getenv(name)
 static const int NERF_GEMM_WGS = env_int("PP_NERF_GEMM_WGS", 256);     // persistent work-groups per column block (measured: 256 = 512 > 384 > 128)
 static const int NERF_GEMM_WGS_WIDE = 512;   // 128 x 256 tiles: 2 resident per CU (55 KB LDS, ~220 registers)
 static const int NERF_TN_CH = env_int("PP_NERF_TN_CH", 64);           // rows per LDS chunk of the weight-gradient GEMM (32 | 64)
+static const int NERF_TN_SPLIT_WGS = env_int("PP_NERF_TN_SPLIT_WGS", 64);   // row splits of the split-precision weight-gradient kernel
 static const int NERF_TN_WGS = env_int("PP_NERF_TN_WGS", 128);        // row splits of a weight-gradient block: 128 x 4 blocks = 2 work-groups per CU, one round
 
 // PP_NERF_BN=256 selects 128 x 256 tiles (activation tile read once, half the barriers per MFMA).  Measured SLOWER on
@@ -536,6 +537,7 @@ static int nerf_wide_tiles() {
 // against fp64 equal to the fp32 matrix instructions', a third of their matrix-pipe time); the weight-gradient GEMMs use the
 // fp32 matrix instructions.  PP_NERF_SPLIT=0 puts the NT GEMMs on the fp32 instructions as well (A/B runs, bisecting).
 static const bool NERF_SPLIT = env_flag("PP_NERF_SPLIT", true);
+static const bool NERF_SPLIT_TN = env_flag("PP_NERF_SPLIT_TN", true);    // weight-gradient products as three fp16 products too
 // One-bit ReLU masks (pp_gemm.h gemm_epilogue): the forward epilogue packs a lane's 16 rows of a column into a 16-bit word,
 // the data-gradient epilogue reads that word instead of 16 floats of the forward activation.  Neutral for the exact-fp32
 // path (12.1 vs 12.0 ms at 3072 x 128 samples), -11..-17 % with the split-precision path.  PP_NERF_BITMASK=0 switches them off.
@@ -583,9 +585,15 @@ static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, i
 }
 
 static void nerf_gemm_tn(hipStream_t st, const float* Y, int ldy, int N, const float* X, int ldx, int Kx, float* Wbar,
-                         float* bbar, const int32_t* count, int rows) {
+                         float* bbar, const int32_t* count, int rows, const float* y_max = nullptr, const float* x_max = nullptr) {
   const int blocks = (N / 128) * pp_div_up(Kx, 128);
-  dim3 g(NERF_TN_WGS * 4 / blocks, blocks), b(256);       // ~ 4 x NERF_TN_WGS work-groups whatever the block count (2, 3, 4 or 6)
+  dim3 b(256);
+  if (NERF_SPLIT && NERF_SPLIT_TN && y_max && x_max) {     // one work-group per CU measured best (3.69 vs 3.85 ms at two)
+    dim3 gs(NERF_TN_SPLIT_WGS * 4 / blocks, blocks);
+    hipLaunchKernelGGL(k_gemm_tn_split, gs, b, 0, st, Y, ldy, X, ldx, Kx, Wbar, ldx, bbar, count, rows, y_max, x_max);
+    return;
+  }
+  dim3 g(NERF_TN_WGS * 4 / blocks, blocks);               // ~ 4 x NERF_TN_WGS work-groups whatever the block count (2, 3, 4 or 6)
   if (NERF_TN_CH == 64)
     hipLaunchKernelGGL((k_gemm_tn<1, 64>), g, b, 0, st, Y, ldy, X, ldx, Kx, Wbar, ldx, bbar, count, 1, rows);
   else
@@ -676,7 +684,7 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
   float* dH = Q;                                   // [M][128]
   hipLaunchKernelGGL(k_nerf_rgb_bwd, dim3(pp_div_up(M, NERF_STRIP)), b, 0, st, params + L.r1, A.h, rgb_samples, g_rgb_samples,
                      M, dH, params_grad + L.r1, params_grad + L.br1, slot(MX_DH));
-  nerf_gemm_tn(st, dH, 128, 128, A.a[7], 288, 288, params_grad + L.r0, params_grad + L.br0, count, M);
+  nerf_gemm_tn(st, dH, 128, 128, A.a[7], 288, 288, params_grad + L.r0, params_grad + L.br0, count, M, slot(MX_DH), slot(MX_A0 + 7));
   hipLaunchKernelGGL(k_nerf_ray_sum, dim3(R), dim3(128), 0, st, dH, R, S, dHsum, slot(MX_DHSUM));
   nerf_gemm<EPI_PLAIN>(st, dHsum, 128, R0T + 256 * 128, 128, 128, 32, nullptr, nullptr, 0, dView, 32, count, R, slot(MX_DHSUM),
                        slot(MX_R0), nullptr);
@@ -685,7 +693,7 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
                       slot(MX_P), A.bits[7]);
   hipLaunchKernelGGL(k_nerf_density_bwd, dim3(pp_div_up(M, NERF_DSTRIP)), dim3(1024), 0, st, A.a[6], A.raw, g_density_samples, M, P,
                      params_grad + L.wd, params_grad + L.bd, slot(MX_P));
-  nerf_gemm_tn(st, P, 288, 256, A.a[6], 256, 256, params_grad + L.w[7], params_grad + L.b[7], count, M);
+  nerf_gemm_tn(st, P, 288, 256, A.a[6], 256, 256, params_grad + L.w[7], params_grad + L.b[7], count, M, slot(MX_P), slot(MX_A0 + 6));
   nerf_gemm<EPI_MASK>(st, P, 288, WT[7], 288, 288, 256, nullptr, A.a[6], 256, Q, 256, count, M, slot(MX_P), slot(MX_W0 + 7),
                       slot(MX_DY6), A.bits[6]);
   float* cur = Q;
@@ -693,7 +701,8 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
   for (int l = 6; l >= 1; --l) {                   // cur = d(pre-activation of layer l), [M][256]
     const float* x = A.a[l - 1];
     const int ldx = NERF_OUT_LD[l - 1];            // 320 for layer 4's input (features + skip columns)
-    nerf_gemm_tn(st, cur, 256, 256, x, ldx, NERF_IN_LD[l], params_grad + L.w[l], params_grad + L.b[l], count, M);
+    nerf_gemm_tn(st, cur, 256, 256, x, ldx, NERF_IN_LD[l], params_grad + L.w[l], params_grad + L.b[l], count, M,
+                 slot(MX_DY6 + 6 - l), slot(MX_A0 + l - 1));
     nerf_gemm<EPI_MASK>(st, cur, 256, WT[l], 256, 256, 256, nullptr, x, ldx, nxt, 256, count, M, slot(MX_DY6 + 6 - l),
                         slot(MX_W0 + l), slot(MX_DY6 + 7 - l), A.bits[l - 1]);
     if (l == 4)                                    // skip columns: gradient of the encoding, no activation in between
@@ -701,7 +710,8 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
                            slot(MX_DY6 + 2), slot(MX_W0 + 4), nullptr);
     float* t = cur; cur = nxt; nxt = t;
   }
-  nerf_gemm_tn(st, cur, 256, 256, A.enc, 64, 64, params_grad + L.w[0], params_grad + L.b[0], count, M);
+  nerf_gemm_tn(st, cur, 256, 256, A.enc, 64, 64, params_grad + L.w[0], params_grad + L.b[0], count, M, slot(MX_DY6 + 6),
+               slot(MX_ENC));
   nerf_gemm<EPI_PLAIN>(st, cur, 256, WT[0], 256, 256, 64, nullptr, nullptr, 0, dEnc0, 64, count, M, slot(MX_DY6 + 6),
                        slot(MX_W0), nullptr);
   hipLaunchKernelGGL(k_nerf_encode_bwd, dim3(R), b, 0, st, A.enc, dEnc0, dEncS, dView, A.a[7], ray, depth, R, S, g_center,
