@@ -123,11 +123,13 @@ __global__ __launch_bounds__(256) void k_nerf_encode(const float* __restrict__ c
 // (the sines / cosines and the view encoding are bounded by 1) -> operand-maximum slots of the three consumers
 __global__ __launch_bounds__(256) void k_nerf_enc_bound(const float* __restrict__ center, const float* __restrict__ ray,
                                                         const float* __restrict__ depth, int R, int S, float* __restrict__ mx) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // one wavefront per ray
   float v = 1.f;
   if (r < R) {
-    float t0 = depth[(size_t)r * S], t1 = t0;           // smallest / largest depth of the ray, whatever the sample order
-    for (int i = 1; i < S; ++i) { const float t = depth[(size_t)r * S + i]; t0 = fminf(t0, t); t1 = fmaxf(t1, t); }
+    float t0 = 3.0e38f, t1 = -3.0e38f;            // smallest / largest depth of the ray, whatever the sample order
+    for (int i = lane; i < S; i += 64) { const float t = depth[(size_t)r * S + i]; t0 = fminf(t0, t); t1 = fmaxf(t1, t); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { t0 = fminf(t0, __shfl_xor(t0, o, 64)); t1 = fmaxf(t1, __shfl_xor(t1, o, 64)); }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float o = center[r * 3 + c], d = ray[r * 3 + c];
@@ -142,10 +144,10 @@ __global__ __launch_bounds__(256) void k_nerf_enc_bound(const float* __restrict_
 // largest |w| of the nine GEMM weight matrices (blockIdx.x selects; the last feature layer includes its density row)
 struct NerfWmaxJobs { const float* src[9]; int n[9]; };
 __global__ __launch_bounds__(256) void k_nerf_wmax(NerfWmaxJobs J, float* __restrict__ mx) {
-  const int q = blockIdx.x;
+  const int q = blockIdx.y;
   const float* __restrict__ p = J.src[q];
   float v = 0.f;
-  for (int i = threadIdx.x; i < J.n[q]; i += 256) v = fmaxf(v, fabsf(p[i]));
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < J.n[q]; i += gridDim.x * 256) v = fmaxf(v, fabsf(p[i]));
   pp_record_max(mx + MX_W0 + q, v);
 }
 
@@ -297,16 +299,21 @@ __global__ void k_nerf_wd_column(const float* __restrict__ wd, float* __restrict
   for (int c = 257; c < 288; ++c) w7t[(size_t)k * 288 + c] = 0.f;
 }
 
-// dHsum[r][j] = sum over the S samples of ray r of dH[m][j]
-__global__ __launch_bounds__(128) void k_nerf_ray_sum(const float* __restrict__ dH, int R, int S, float* __restrict__ out,
+// dHsum[r][j] = sum over the S samples of ray r of dH[m][j] ; 4 wavefront pairs per ray walk every 4th sample
+__global__ __launch_bounds__(512) void k_nerf_ray_sum(const float* __restrict__ dH, int R, int S, float* __restrict__ out,
                                                       float* __restrict__ mx_sum) {
-  const int r = blockIdx.x, j = threadIdx.x;
-  if (r >= R) return;
+  __shared__ float red[4][128];
+  const int r = blockIdx.x, j = threadIdx.x & 127, q = threadIdx.x >> 7;
   float acc = 0.f;
   const float* p = dH + (size_t)r * S * 128 + j;
-  for (int s = 0; s < S; ++s) acc += p[(size_t)s * 128];
-  out[(size_t)r * 128 + j] = acc;
-  if (mx_sum) pp_record_max(mx_sum, fabsf(acc));
+  for (int s = q; s < S; s += 4) acc += p[(size_t)s * 128];
+  red[q][j] = acc;
+  __syncthreads();
+  if (q == 0) {
+    acc = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+    out[(size_t)r * 128 + j] = acc;
+    if (mx_sum) pp_record_max(mx_sum, fabsf(acc));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ compositing
@@ -616,8 +623,8 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
     for (int l = 0; l < 7; ++l) { J.src[l] = params + L.w[l]; J.n[l] = 256 * NERF_IN_LD[l]; }
     J.src[7] = params + L.wd; J.n[7] = 257 * 256;
     J.src[8] = params + L.r0; J.n[8] = 128 * 288;
-    hipLaunchKernelGGL(k_nerf_wmax, dim3(9), dim3(256), 0, st, J, mx);
-    hipLaunchKernelGGL(k_nerf_enc_bound, dim3(pp_div_up(n_rays, 256)), dim3(256), 0, st, center, ray, depth, n_rays, n_samples, mx);
+    hipLaunchKernelGGL(k_nerf_wmax, dim3(32, 9), dim3(256), 0, st, J, mx);
+    hipLaunchKernelGGL(k_nerf_enc_bound, dim3(pp_div_up(n_rays, 4)), dim3(256), 0, st, center, ray, depth, n_rays, n_samples, mx);
   }
   hipLaunchKernelGGL(k_nerf_encode, dim3(pp_div_up(M, 4)), dim3(256), 0, st, center, ray, depth, bands, M,
                      n_samples, A.enc, A.a[3], A.a[7]);
@@ -685,7 +692,7 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
   hipLaunchKernelGGL(k_nerf_rgb_bwd, dim3(pp_div_up(M, NERF_STRIP)), b, 0, st, params + L.r1, A.h, rgb_samples, g_rgb_samples,
                      M, dH, params_grad + L.r1, params_grad + L.br1, slot(MX_DH));
   nerf_gemm_tn(st, dH, 128, 128, A.a[7], 288, 288, params_grad + L.r0, params_grad + L.br0, count, M, slot(MX_DH), slot(MX_A0 + 7));
-  hipLaunchKernelGGL(k_nerf_ray_sum, dim3(R), dim3(128), 0, st, dH, R, S, dHsum, slot(MX_DHSUM));
+  hipLaunchKernelGGL(k_nerf_ray_sum, dim3(R), dim3(512), 0, st, dH, R, S, dHsum, slot(MX_DHSUM));
   nerf_gemm<EPI_PLAIN>(st, dHsum, 128, R0T + 256 * 128, 128, 128, 32, nullptr, nullptr, 0, dView, 32, count, R, slot(MX_DHSUM),
                        slot(MX_R0), nullptr);
   // last feature layer: columns 0..255 through the colour head, column 256 from the density
