@@ -398,3 +398,46 @@ def test_fp32_instruction_mode_passes_the_reference_fixture():
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout
+
+
+def test_correspondence_loss_through_the_hip_render_path():
+    """bg_losses.correspondence_loss: depths rendered by the kernels at matched pixels of a pair (coarse + fine), both
+    re-projection directions; equals the explicit composition of its (reference-pinned) pieces and sends gradients to both
+    networks and both poses."""
+    from poseprobe_amd import bg_losses, bg_nerf, synthetic as syn
+    opt = bg_nerf.default_options(sample_intvs=24)
+    opt.nerf.fine_sampling, opt.nerf.sample_intvs_fine = True, 16
+    opt.nerf.ratio_start_fine_sampling_at_x, opt.max_iter = None, 1000
+    opt.update(renderrepro_do_pixel_reprojection_check=False, renderrepro_do_depth_reprojection_check=False,
+               renderrepro_pixel_reprojection_thresh=20., renderrepro_depth_reprojection_thresh=0.1, diff_loss_type='huber')
+    torch.manual_seed(31)
+    sr = bg_nerf.SceneRenderer(opt, device='cuda')
+    for net in (sr.nerf, sr.nerf_fine):
+        net.progress.data.fill_(0.7)
+        with torch.no_grad():
+            net.mlp_feat[-1].bias[0] += 2.0
+    H, W, N = 32, 48, 40
+    views = syn.make_views(2, H, W, seed=4)
+    poses = torch.tensor(views['w2c'][:, :3, :4]).float().cuda().requires_grad_(True)
+    intr = torch.tensor(views['Ks']).float().cuda()
+    g = torch.Generator().manual_seed(8)
+    pix_self = (torch.rand(N, 2, generator=g) * torch.tensor([W - 1., H - 1.])).cuda()
+    pix_other = (pix_self.cpu() + torch.randn(N, 2, generator=g) * 3).cuda()
+    conf = torch.rand(N, 1, generator=g).cuda()
+    rand = [torch.rand(2, N, 24, 1, generator=g), torch.rand(17, generator=g)]
+    loss, stats, rets = bg_losses.correspondence_loss(sr, opt, poses, intr, pix_self, pix_other, conf, H, W, (0.5, 3.0),
+                                                      iteration=500, rand=rand)
+    assert 'depth_fine' in rets and torch.isfinite(loss)
+    bottom = torch.tensor([[0., 0., 0., 1.]]).cuda()
+    T = torch.cat([poses[1], bottom]) @ bg_losses.pose_inverse_4x4(torch.cat([poses[0], bottom]))
+    ref = 0.
+    for key in ('depth', 'depth_fine'):
+        ds, do = rets[key][0].squeeze(-1), rets[key][1].squeeze(-1)
+        ref = ref + bg_losses.reprojection_loss(opt, pix_self, ds, intr[0], pix_other, do, intr[1], T, conf)[0]
+        ref = ref + bg_losses.reprojection_loss(opt, pix_other, do, intr[1], pix_self, ds, intr[0], bg_losses.pose_inverse_4x4(T), conf)[0]
+    assert_close(loss, (ref / 4.).detach().cpu(), rtol=1e-6, name='loss composition')
+    loss.backward()
+    assert torch.isfinite(poses.grad).all() and float(poses.grad.abs().max()) > 0
+    for net in (sr.nerf, sr.nerf_fine):
+        gmax = max(float(p.grad.abs().max()) for n, p in net.named_parameters() if n != 'progress')
+        assert np.isfinite(gmax) and gmax > 0
