@@ -1,6 +1,7 @@
 // Scene branch (lib/bg_nerf): the 8 x 256 NeRF MLP with BARF positional encoding and exp-cumsum compositing, forward and
-// backward, fp32 in memory and fp32-accurate on the CDNA4 matrix cores (forward / data-gradient products as three fp16
-// products with fp32 accumulation, weight-gradient products on the fp32 instructions; PP_NERF_SPLIT=0: fp32 instructions only).
+// backward.  fp32 in memory, fp32 accumulation, fp32-accurate matrix products: every product runs as three fp16 products on
+// v_mfma_f32_32x32x16_f16 (pp_gemm_split.h; error against fp64 equal to the fp32 matrix instructions'); PP_NERF_SPLIT=0
+// selects the fp32 instructions (pp_gemm.h) for all of them, PP_NERF_SPLIT_TN=0 for the weight gradients only.
 //
 //   reference: lib/bg_nerf/source/models/frequency_nerf.py
 //     :42-69    FrequencyEmbedder          (sin / cos of 2^l * pi * x, layout [coordinate][sin|cos][band])
@@ -9,12 +10,14 @@
 //     :239-266  positional_encoding        (coarse-to-fine band weights)
 //     :290-343  composite                  (alpha = 1 - exp(-sigma * dist), T = exp(-exclusive cumsum), weights = T * alpha)
 //
-// A 256-wide fp32 layer carries 64 FLOP per byte of activation traffic - twice the machine ridge - so unlike the 128-wide
-// object-branch MLPs this network is bound by the matrix pipe even when it runs layer by layer: every layer is one launch
-// of the persistent 128 x 128-tile NT GEMM of pp_gemm.h (two column blocks over the same row tiles, which therefore meet in
-// L2), all activations stay resident in HBM for the backward pass (9.3 KB per sample, 3.7 GB at 3072 rays x 128 samples),
-// and the data- and weight-gradient GEMMs of the backward pass reuse the same kernels.  The thin ends of the network
-// (encoding, density head, 128 -> 3 colour head, compositing, encoding backward) are bandwidth-bound streaming kernels.
+// A 256-wide layer carries 64 FLOP per byte of fp32 activation traffic - twice the machine ridge on the fp32 matrix
+// instructions - so unlike the 128-wide object-branch MLPs this network gains nothing from layer fusion: every layer is one
+// launch of a persistent 128 x 128-tile NT GEMM (two column blocks over the same row tiles, which meet in L2), all
+// activations stay resident in HBM for the backward pass (9.3 KB per sample, 3.7 GB at 3072 rays x 128 samples), ReLU masks
+// as one bit per activation, and the data- and weight-gradient GEMMs of the backward pass use the same tile structure.
+// With the three-product scheme the matrix time drops to a third and the GEMMs become load-bound.  The thin
+// ends of the network (encoding, density head, 128 -> 3 colour head, compositing, encoding backward) are bandwidth-bound
+// streaming kernels.
 #include "pp_common.h"
 #include "pp_gemm.h"
 #include "pp_gemm_split.h"
@@ -269,16 +272,7 @@ __global__ __launch_bounds__(1024) void k_nerf_density_bwd(const float* __restri
   }
 }
 
-// dst[c * ldd + r] = src[r * lds + c]
-__global__ __launch_bounds__(256) void k_nerf_transpose(const float* __restrict__ src, int lds, int rows, int cols,
-                                                        float* __restrict__ dst, int ldd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * cols) return;
-  const int c = i / rows, r = i - c * rows;
-  dst[(size_t)c * ldd + r] = src[(size_t)r * lds + c];
-}
-
-// all nine weight matrices of the backward pass in ONE launch: blockIdx.y selects the matrix
+// dst[c * ldd + r] = src[r * lds + c] for all nine weight matrices of the backward pass in ONE launch: blockIdx.y selects the matrix
 struct NerfTransposeJobs { const float* src[9]; float* dst[9]; int lds[9], rows[9], cols[9], ldd[9]; };
 __global__ __launch_bounds__(256) void k_nerf_transpose_all(NerfTransposeJobs J) {
   const int q = blockIdx.y;
