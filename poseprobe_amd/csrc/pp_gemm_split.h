@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, PP_SPLIT_WAVES) void k_gemm128s(const float* _
 // ------------------------------------------------------------------------------------------------------------------
 #define LDC 72        // halfs per LDS column: 64 rows + 8 (144 B)
 
-__global__ __launch_bounds__(256) void k_gemm_tn_split(const float* __restrict__ Y_, int ldy, const float* __restrict__ X_, int ldx,
+static __global__ __launch_bounds__(256) void k_gemm_tn_split(const float* __restrict__ Y_, int ldy, const float* __restrict__ X_, int ldx,
                                                        int Kx_, float* __restrict__ Wbar_, int ldwb, float* __restrict__ bbar_,
                                                        const int32_t* __restrict__ count, int rcap,
                                                        const float* __restrict__ y_max, const float* __restrict__ x_max) {
@@ -310,4 +310,147 @@ __global__ __launch_bounds__(256) void k_gemm_tn_split(const float* __restrict__
       atomicAdd(&bbar[tid], sum);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Self-scaling variant of k_gemm_tn_split for callers that have no operand maxima (the object branch's layer-fused kernels
+// do not record any):  Wbar[n][k] += sum_r Y[r][n] X[r][k],  n < 128, k < Kx <= 128, Y and X with 128 / ldx floats per row.
+// Every 64-row chunk reduces max|Y|, max|X| of what it is about to stage (registers -> wave shuffle -> 8 floats of LDS) and
+// converts with the RUNNING MINIMUM of the chunk scales; when a chunk lowers the scale, the accumulators are multiplied by
+// the (power-of-two, hence exact) ratio first - the online-rescaling trick of streaming softmax.  No chunk is ever converted
+// with a scale above its own safe one, so nothing overflows, and the result carries the precision of a single scale derived
+// from the work-group's whole row range.  One extra barrier per chunk.  gridDim.x = row splits.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pp_split_scale_or_huge(float mx) {
+  if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.7e38f;       // an all-zero chunk puts no constraint on the scale
+  int e;
+  frexpf(mx, &e);
+  return ldexpf(1.f, 15 - e);
+}
+
+static __global__ __launch_bounds__(256) void k_gemm_tn_split_auto(const float* __restrict__ Y, const float* __restrict__ X, int ldx, int Kx,
+                                                            float* __restrict__ Wbar, int ldwb,
+                                                            const int32_t* __restrict__ count, int rmul, int rcap) {
+  constexpr int CH = 64;
+  __shared__ _Float16 Yh[128 * LDC], Yl[128 * LDC], Xh[128 * LDC], Xl[128 * LDC];
+  __shared__ float mxs[4][2];
+  const int R = min(count[0] * rmul, rcap);
+  const int rows_per_wg = ((R + (int)gridDim.x - 1) / (int)gridDim.x + CH - 1) / CH * CH;
+  const int rb = blockIdx.x * rows_per_wg;
+  if (rb >= R) return;
+  const int re = min(rb + rows_per_wg, R);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int c4 = tid & 31, rblk = tid >> 5;
+  const int kx4 = Kx >> 2;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+  float4 ry[8], rx[8];
+  auto load_rows = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int gr = r0 + rblk * 8 + i;
+      ry[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rx[i] = ry[i];
+      if (gr < re) {
+        ry[i] = *reinterpret_cast<const float4*>(Y + (size_t)gr * 128 + c4 * 4);
+        if (c4 < kx4) rx[i] = *reinterpret_cast<const float4*>(X + (size_t)gr * ldx + c4 * 4);
+      }
+    }
+  };
+  auto store_col = [&](const float4 (&r)[8], int j, float s, _Float16* Th, _Float16* Tl) {
+    pp_half8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float x = (j == 0 ? r[i].x : j == 1 ? r[i].y : j == 2 ? r[i].z : r[i].w) * s;
+      const _Float16 hh = (_Float16)x;
+      h[i] = hh;
+      l[i] = (_Float16)(x - (float)hh);
+    }
+    const int o = (c4 * 4 + j) * LDC + ((rblk ^ (c4 & 7)) * 8);
+    *reinterpret_cast<pp_half8*>(Th + o) = h;
+    *reinterpret_cast<pp_half8*>(Tl + o) = l;
+  };
+  float SY = 1.7e38f, SX = 1.7e38f;             // running (minimum) scales; "huge" = not constrained yet
+  bool any = false;
+  load_rows(rb);
+  for (int r0 = rb; r0 < re; r0 += CH) {
+    float my = 0.f, mxv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      my = fmaxf(my, fmaxf(fmaxf(fabsf(ry[i].x), fabsf(ry[i].y)), fmaxf(fabsf(ry[i].z), fabsf(ry[i].w))));
+      mxv = fmaxf(mxv, fmaxf(fmaxf(fabsf(rx[i].x), fabsf(rx[i].y)), fmaxf(fabsf(rx[i].z), fabsf(rx[i].w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { my = fmaxf(my, __shfl_xor(my, o, 64)); mxv = fmaxf(mxv, __shfl_xor(mxv, o, 64)); }
+    if (lane == 0) { mxs[wid][0] = my; mxs[wid][1] = mxv; }
+    __syncthreads();                            // chunk maxima visible; previous chunk's fragment reads are done
+    my = fmaxf(fmaxf(mxs[0][0], mxs[1][0]), fmaxf(mxs[2][0], mxs[3][0]));
+    mxv = fmaxf(fmaxf(mxs[0][1], mxs[1][1]), fmaxf(mxs[2][1], mxs[3][1]));
+    const float nSY = fminf(SY, pp_split_scale_or_huge(my)), nSX = fminf(SX, pp_split_scale_or_huge(mxv));
+    if (any && (nSY != SY || nSX != SX)) {      // uniform over the work-group: rescale what has been accumulated so far
+      const float f = (nSY / SY) * (nSX / SX);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[t][u][i] *= f;
+    }
+    SY = nSY; SX = nSX;
+    const float sy = (SY < 1.0e38f) ? SY : 1.f, sx = (SX < 1.0e38f) ? SX : 1.f;   // an operand that was all zero so far: any scale
+    any = any || (SY < 1.0e38f && SX < 1.0e38f);    // from here on the accumulators may be non-zero (both scales are set)
+    store_col(ry, 0, sy, Yh, Yl); store_col(ry, 1, sy, Yh, Yl); store_col(ry, 2, sy, Yh, Yl); store_col(ry, 3, sy, Yh, Yl);
+    store_col(rx, 0, sx, Xh, Xl); store_col(rx, 1, sx, Xh, Xl); store_col(rx, 2, sx, Xh, Xl); store_col(rx, 3, sx, Xh, Xl);
+    __syncthreads();
+    if (r0 + CH < re) load_rows(r0 + CH);
+    if (wc * 64 < Kx) {
+#pragma unroll
+      for (int ks = 0; ks < CH; ks += 16) {
+        pp_half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int col = wr * 64 + t * 32 + l31;
+          const int o = col * LDC + ((((ks >> 3) + lh) ^ ((col >> 2) & 7)) * 8);
+          ah[t] = *reinterpret_cast<const pp_half8*>(Yh + o);
+          al[t] = *reinterpret_cast<const pp_half8*>(Yl + o);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int col = wc * 64 + u * 32 + l31;
+          const int o = col * LDC + ((((ks >> 3) + lh) ^ ((col >> 2) & 7)) * 8);
+          bh[u] = *reinterpret_cast<const pp_half8*>(Xh + o);
+          bl[u] = *reinterpret_cast<const pp_half8*>(Xl + o);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[u], acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[u], acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[u], acc[t][u], 0, 0, 0);
+          }
+      }
+    }
+  }
+  if (!any || !(wc * 64 < Kx)) return;          // nothing but zeros seen, or a wavefront without real columns
+  const float invy = 1.0f / SY, invx = 1.0f / SX;          // applied one after the other: their product may leave the float range
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = wc * 64 + u * 32 + l31;
+      if (k >= Kx) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int n = wr * 64 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        atomicAdd(&Wbar[(size_t)n * ldwb + k], acc[t][u][reg] * invy * invx);
+      }
+    }
 }

@@ -14,6 +14,7 @@
 #include "pp_common.h"
 #include "pp_mlp_fused.h"
 #include "pp_wgrad_asm.inc"
+#include "pp_gemm_split.h"
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -728,9 +729,28 @@ __global__ __launch_bounds__(256) void k_wgrad_chain(WgradLayer LA, WgradLayer L
   wgrad_flush<KXC>(LC.Wbar, accC, wr, wc, l31, lh);
 }
 
+// PP_WGRAD_SPLIT=1 replaces the fp32-instruction chain kernel above by three launches of the self-scaling split-precision
+// kernel.  Parity suite green, but SLOWER on MI355X (1.405 vs 1.356 ms per step): the chain kernel reads each operand once,
+// keeps 192 accumulators resident and is hand-scheduled; three load-bound launches with an extra barrier per chunk are not
+// a match for it.  Off by default; kept as the starting point for a fused split-precision chain.
+static bool wgrad_split_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PP_WGRAD_SPLIT"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
 int pp_launch_wgrad_chain(const float* YA, const float* XA, float* WA, const float* YB, const float* XB, float* WB,
                           const float* YC, const float* XC, float* WC, int kxc, const int32_t* count, int rmul, int rcap,
                           hipStream_t st) {
+  if (wgrad_split_enabled()) {
+    // three launches of the self-scaling split-precision kernel (pp_gemm_split.h): three fp16 products per fp32 product,
+    // error against fp64 equal to the fp32 matrix instructions'; load-bound instead of matrix-pipe bound
+    const int splits = rcap >= 131072 ? 256 : 128;
+    hipLaunchKernelGGL(k_gemm_tn_split_auto, dim3(splits), dim3(256), 0, st, YA, XA, 128, 128, WA, 128, count, rmul, rcap);
+    hipLaunchKernelGGL(k_gemm_tn_split_auto, dim3(splits), dim3(256), 0, st, YB, XB, 128, 128, WB, 128, count, rmul, rcap);
+    hipLaunchKernelGGL(k_gemm_tn_split_auto, dim3(splits), dim3(256), 0, st, YC, XC, kxc, kxc, WC, kxc, count, rmul, rcap);
+    return 0;
+  }
   WgradLayer LA{YA, XA, WA}, LB{YB, XB, WB}, LC{YC, XC, WC};
   const int npairs = pp_div_up(rcap, 2 * TILE_ROWS);
   const int grid = npairs < PP_FUSED_WGS ? npairs : PP_FUSED_WGS;
