@@ -222,6 +222,14 @@ class NeRF(torch.nn.Module):
                                'moving / casting it')
         return self
 
+    def state_dict(self, *args, **kwargs):
+        """Compact copies under the reference's names: the parameters are views into the packed block, and serialising a view
+        would write the whole 2 MB block once per tensor."""
+        sd = super().state_dict(*args, **kwargs)
+        for k in list(sd.keys()):
+            sd[k] = sd[k].clone()
+        return sd
+
     def initialize(self):
         """TensorFlow-style Xavier initialisation (frequency_nerf.py:128-148)."""
         gain = torch.nn.init.calculate_gain('relu')

@@ -441,3 +441,21 @@ def test_correspondence_loss_through_the_hip_render_path():
     for net in (sr.nerf, sr.nerf_fine):
         gmax = max(float(p.grad.abs().max()) for n, p in net.named_parameters() if n != 'progress')
         assert np.isfinite(gmax) and gmax > 0
+
+
+def test_scene_state_dict_is_compact_and_round_trips(tmp_path):
+    """`state_dict()` hands out compact copies (not views of the 2 MB packed block) under the reference's names and shapes;
+    saving and loading it reproduces the network bit for bit."""
+    import os
+    from poseprobe_amd import bg_nerf
+    net, opt = _net(progress=0.42)
+    sd = net.state_dict()
+    assert sd['mlp_feat.0.weight'].shape == (256, 63) and sd['mlp_feat.4.weight'].shape == (256, 319)
+    assert sd['mlp_feat.7.weight'].shape == (257, 256) and sd['mlp_rgb.0.weight'].shape == (128, 283)
+    assert all(v.is_contiguous() for v in sd.values())
+    path = str(tmp_path / 'nerf.pt')
+    torch.save(sd, path)
+    assert os.path.getsize(path) < 3.5e6                      # 0.6 M parameters, not 22 copies of the block
+    net2 = bg_nerf.NeRF(opt, device='cuda')
+    net2.load_state_dict(torch.load(path, map_location='cpu', weights_only=True))
+    assert torch.equal(net2.flat, net.flat) and float(net2.progress) == float(net.progress)
