@@ -163,7 +163,7 @@ def test_scene_engine_step_equals_oracle_adam():
         assert_close(l2, loss, rtol=2e-5 if it == 0 else 5e-4, name=f'loss[{it}]')   # later steps inherit Adam's sensitivity
     for name, p in net.named_parameters():
         if name != 'progress':
-            assert_close(p, P[name], rtol=1e-4, atol=3e-4, name='adam.' + name)          # 10 % of the three lr-sized steps taken
+            assert_close(p, P[name], rtol=1e-4, atol=6e-4, name='adam.' + name)          # 20 % of the three lr-sized steps taken
     # padding of the packed block never moves
     o = net._off
     assert float(net.flat[o[0]:o[0] + 256 * 64].view(256, 64)[:, 63].abs().max()) == 0.0
