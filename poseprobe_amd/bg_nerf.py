@@ -381,6 +381,27 @@ class SceneRenderer:
         return pred
 
 
+    def render_up_to_maxdepth(self, opt, pose, H, W, intr, depth_max, depth_min, pixels, iter=None, mode=None):
+        """Rendering with a different far bound per ray (renderer.py:742-878, sample_depth_diff_max_range_per_ray :880-909):
+        depth_max [B, N]; deterministic samples depth_min + (i + 1) / S * (depth_max - depth_min); the fine network, when
+        active, is evaluated on the SAME samples (only the accumulated transmittance is wanted from this pass)."""
+        center, ray = get_center_and_ray_at_pixels(pose, pixels, intr)
+        S = opt.nerf.sample_intvs
+        steps = (1.0 + torch.arange(S, device=self.device).float())[None, None, :, None] / S
+        depth = steps * (depth_max[..., None, None] - depth_min) + depth_min
+        pred = Options(origins=center, viewdirs=ray)
+        coarse = self.nerf.forward_samples(opt, center, ray, depth, mode=mode)
+        coarse['t'] = depth
+        pred.update(self.nerf.composite(opt, ray, coarse, depth))
+        start = getattr(opt.nerf, 'ratio_start_fine_sampling_at_x', None)
+        skip_fine = start is not None and iter is not None and iter < opt.max_iter * start
+        if opt.nerf.fine_sampling and not skip_fine:
+            fine = self.nerf_fine.forward_samples(opt, center, ray, depth, mode=mode)
+            fine['t'] = depth
+            fine = self.nerf_fine.composite(opt, ray, fine, depth)
+            pred.update({k + '_fine': v for k, v in fine.items()})
+        return pred
+
     @torch.no_grad()
     def render_by_slices(self, opt, pose, H, W, intr, depth_range, iter=None, mode=None):
         """Full H x W images in slices of `opt.nerf.rand_rays` rays (renderer.py:629-663): per-ray outputs concatenated along

@@ -459,3 +459,43 @@ def test_scene_state_dict_is_compact_and_round_trips(tmp_path):
     net2 = bg_nerf.NeRF(opt, device='cuda')
     net2.load_state_dict(torch.load(path, map_location='cpu', weights_only=True))
     assert torch.equal(net2.flat, net.flat) and float(net2.progress) == float(net.progress)
+
+
+def test_depth_consistency_loss_through_the_hip_render_path():
+    """bg_losses.depth_consistency_loss (depth_cons_loss.py:128-330): pseudo ground truth from a training view, visibility by
+    render_up_to_maxdepth in a virtual view, weighted Huber on the depths rendered there; gradients reach both networks, the
+    poses are detached as in the reference; points projected outside the virtual image give the zero loss."""
+    from poseprobe_amd import bg_losses, bg_nerf, synthetic as syn
+    opt = bg_nerf.default_options(sample_intvs=24)
+    opt.nerf.fine_sampling, opt.nerf.sample_intvs_fine = True, 16
+    opt.nerf.ratio_start_fine_sampling_at_x, opt.max_iter = 0.3, 1000
+    opt.update(diff_loss_type='huber')
+    torch.manual_seed(17)
+    sr = bg_nerf.SceneRenderer(opt, device='cuda')
+    for net in (sr.nerf, sr.nerf_fine):
+        net.progress.data.fill_(0.8)
+    H, W, N = 32, 48, 64
+    views = syn.make_views(3, H, W, seed=9)
+    poses = torch.tensor(views['w2c'][:, :3, :4]).float().cuda().requires_grad_(True)
+    intr = torch.tensor(views['Ks']).float().cuda()
+    g = torch.Generator().manual_seed(2)
+    pix = (torch.rand(N, 2, generator=g) * torch.tensor([W - 1., H - 1.])).cuda()
+    # render_up_to_maxdepth: S deterministic samples ending exactly at each ray's own far bound
+    dmax = (1.0 + torch.rand(1, N, generator=g)).cuda()
+    ret = sr.render_up_to_maxdepth(opt, poses[:1].detach(), H, W, intr[:1], dmax, 0.5, pix[None], iter=900, mode='train')
+    t = ret['t'][0, :, :, 0]
+    assert_close(t[:, -1], dmax[0].cpu(), rtol=1e-6, name='last sample = per-ray far bound')
+    assert_close(t[:, 0], (0.5 + (dmax[0] - 0.5) / 24).cpu(), rtol=1e-6, name='first sample')
+    assert 'all_cumulated_fine' in ret and float(ret['all_cumulated'].max()) <= 1.0
+    loss, stats = bg_losses.depth_consistency_loss(sr, opt, poses, intr, H, W, (0.5, 3.0), iteration=900, id_self=1,
+                                                   pixels_ref=pix, w=0.6)
+    assert torch.isfinite(loss) and float(loss) > 0 and stats['nbr_px_sampling'] == N
+    loss.backward()
+    assert poses.grad is None                                   # pseudo ground truth and virtual pose use detached poses
+    for net in (sr.nerf, sr.nerf_fine):
+        gmax = max(float(p.grad.abs().max()) for n, p in net.named_parameters() if n != 'progress')
+        assert np.isfinite(gmax) and gmax > 0
+    far = torch.tensor([[50., 50., -5.]] * 8).cuda()            # behind / outside the virtual camera: nothing survives
+    bottom = torch.tensor([[0., 0., 0., 1.]]).cuda()
+    z, _ = bg_losses.depth_consistency_loss_at_pose(sr, opt, torch.cat([poses[0].detach(), bottom]), intr[0], far, H, W, 0.5, 900)
+    assert float(z) == 0.0 and z.requires_grad

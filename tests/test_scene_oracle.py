@@ -101,3 +101,20 @@ def test_correspondence_loss_helpers_match_reference():
             if label + '.' + k in d:
                 assert_close(stats[k], d[label + '.' + k], rtol=1e-6, name=label + '.' + k)
     assert 0.05 < float(d['filtered.perc_val_pix_rep']) < 0.95        # the pixel filter actually selects
+
+
+def test_depth_consistency_geometry_matches_reference():
+    """bg_losses.backproject_to_3d / project / nearest_pose_id / sample_virtual_pose against the reference's own function bodies
+    (oracle/make_golden.py: gen_scene_depthcons)."""
+    from poseprobe_amd import bg_losses
+    d = load('scene_depthcons.npz')
+    K, P, Pc2w = torch.tensor(d['K']), torch.tensor(d['P']), torch.tensor(d['P_c2w'])
+    assert_close(bg_losses.pose_inverse_4x4(P), d['P_c2w'], rtol=1e-6, atol=1e-6, name='batched pose_inverse_4x4')
+    pts = bg_losses.backproject_to_3d(torch.tensor(d['pix']), torch.tensor(d['depth']), K[1], Pc2w[1])
+    assert_close(pts, d['pts3d'], rtol=1e-5, atol=1e-6, name='backproject_to_3d')
+    px, dj = bg_losses.project(pts, P[3], K[3])
+    assert_close(px, d['proj_px'], rtol=1e-5, atol=1e-4, name='project: pixels')
+    assert_close(dj, d['proj_depth'], rtol=1e-5, atol=1e-6, name='project: depth')
+    assert [bg_losses.nearest_pose_id(Pc2w, i) for i in range(int(d['V']))] == [int(x) for x in d['nearest']]
+    virt = bg_losses.sample_virtual_pose(Pc2w, 2, P[2], float(d['w']))
+    assert_close(virt, d['virtual_w2c'], rtol=1e-5, atol=1e-6, name='virtual pose')
