@@ -4,36 +4,74 @@ the BASELINE.json workload: DTU-scan1-like 3 views of 400x400, 160^3 grid, 186 s
 GPU (weak scaling: global batch = 1024 * n_gpus), fp32, synthetic inputs resident in HBM.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
-  roofline     - the dominant kernel (fused TV+Adam pass over the dense k0 grid, HBM bound): algorithmic bytes per
-                 launch (384 B/voxel) / mean launch duration measured with HIP events on the launch stream
-  cpu_baseline - the oracle (CPU restatement, "port") timed on this host's cores for a bounded sample (N=1, rank 0)
+With N > 1 and no RANK in the environment the script starts its own N ranks (one `python -m torch.distributed.run`
+child, before anything touches the GPU), relays rank 0's JSON line and exits with the child's return code; the driver's
+own `torch.distributed.run` launch (RANK set) runs the ranks directly.
+
+Prints ONE JSON line on rank 0 (driver contract).  Objects besides the contract's scalar fields:
+  roofline          the longest kernel of the timed step, priced live with HIP events inside the timed region (the
+                    warp-MLP data-gradient kernel on fp32 MFMA, or the fused TV + Adam grid pass on HBM)
+  roofline_grid     the fused TV + Adam pass over the dense k0 grid against the HBM peak (always reported)
+  roofline_mlp      both MLP chains as a whole (6 kernels) against the fp32 MFMA peak; `kernels` lists each of them
+  dual_branch       BASELINE config 2 as the reference runs it: object step + scene branch (bg_nerf) sharing the poses;
+                    its rays/s and ms/step are repeated as top-level fields `dual_branch_rays_per_s`, `dual_branch_ms_per_step`
+  roofline_scene    the scene branch's forward + backward GEMM chains against the fp16 MFMA pipe they issue on
+  cpu_baseline      the oracle (CPU restatement, "port") timed on this host's cores for a bounded sample (N=1, rank 0)
+  psnr_parity       oracle and HIP engine trained from one initialisation with the same per-step rays and jitter; PSNR of
+                    both on held-out pixels and their difference (BASELINE metric: "PSNR parity", <= 0.1 dB)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from poseprobe_amd import synthetic as syn            # noqa: E402
-from poseprobe_amd.engine import SceneConfig, TrainEngine   # noqa: E402
-
 HBM_PEAK_GBS = 8000.0       # MI355X spec (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+FP32_MFMA_PEAK_TF = 157.3   # dense fp32 MFMA (MI355X_MICROARCH.md)
+FP16_MFMA_PEAK_TF = 2500.0  # dense fp16 MFMA (MI355X_MICROARCH.md: ~2.5 PFLOP/s; never the 2:1-sparsity figure)
 GRID_BYTES_PER_VOXEL = 384  # fused pass, C=12 fp32: read p,g,m,v (192) + write p',m,v,g=0 (192)
 
 
+# ------------------------------------------------------------------------------------------------ self launch
+def launch_ranks(n_gpus, argv, device_count=None, launcher=None, out=None):
+    """Start `n_gpus` ranks of this script on one node and relay rank 0's stdout.  Must run before the calling process has
+    touched the GPU (nothing is re-exec'ed: the ranks are children).  -> the child's return code.
+    device_count: callable returning the number of visible GPUs (default torch.cuda.device_count, which does not
+    initialise the GPU); launcher: argv prefix of the process that spawns the ranks (default torch.distributed.run)."""
+    out = out or sys.stdout
+    if device_count is None:
+        import torch
+        device_count = torch.cuda.device_count
+    have = int(device_count())
+    if have < n_gpus:
+        sys.stderr.write(f'bench.py: --gpus {n_gpus} requested but only {have} GPU(s) are visible on this node\n')
+        return 3
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    if launcher is None:
+        launcher = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_gpus}',
+                    '--master-addr', '127.0.0.1', '--master-port', str(port)]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC only on this host driver (RCCL needs it)
+    proc = subprocess.Popen(list(launcher) + [os.path.abspath(__file__)] + list(argv), stdout=subprocess.PIPE, env=env)
+    for line in proc.stdout:
+        out.write(line.decode(errors='replace'))
+        out.flush()
+    return proc.wait()
+
+
 def pmc_traffic(grid, voxels, sparse):
-    """HBM bytes per launch of k_grid_tv_adam from the committed rocprofv3 PMC passes (profiles/r01_grid_traffic*.json:
+    """HBM bytes per launch of k_grid_tv_adam from the COMMITTED rocprofv3 PMC passes (profiles/r01_grid_traffic*.json:
     FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KB -> bytes), only when it was collected for this grid size and for
-    this variant of the pass (dense / sparse-gradient)."""
+    this variant of the pass (dense / sparse-gradient).  Not measured by this run (PMC needs its own rocprofv3 pass)."""
     try:
         name = 'r01_grid_traffic_sparse.json' if sparse else 'r01_grid_traffic.json'
         rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
@@ -46,6 +84,8 @@ def pmc_traffic(grid, voxels, sparse):
 
 def init_engine_params(eng, cfg, seed):
     """Random-init parameters of the reference's architecture (cube-init SDF, k0~N(0,.1), warp last layer N(0,1e-2))."""
+    import torch
+    from poseprobe_amd import synthetic as syn
     from poseprobe_amd.params_init import reference_like_params
     P = reference_like_params(cfg, seed)
     eng.load_reference_params(P['k0'], P['sdf'], P['sdf_alpha'], P['sdf_beta'], P['rgbnet'], P['warp'],
@@ -53,10 +93,14 @@ def init_engine_params(eng, cfg, seed):
     return P
 
 
+# ------------------------------------------------------------------------------------------------ CPU legs (the oracle)
 def cpu_baseline(G, H, W, V, n_rand, views, budget_s=20.0):
     """Oracle train step on the host cores: bounded sample of the SAME workload.  torch-CPU stops scaling (and then
     degrades: 128 threads are 3x slower than 32 for these op sizes) beyond ~32 threads, so at most 32 are used."""
+    import numpy as np
+    import torch
     from oracle import voxurf_oracle as O
+    from poseprobe_amd import synthetic as syn
     threads_before = torch.get_num_threads()
     torch.set_num_threads(min(32, threads_before))
     rs = syn.range_shape()
@@ -86,6 +130,8 @@ def cpu_baseline(G, H, W, V, n_rand, views, budget_s=20.0):
 
 def cpu_baseline_scene(V, threads, n_pix=341, S=128, reps=3):
     """The scene branch's coarse pass (forward, loss, backward) of the oracle on the same host cores, beside `dual_branch`."""
+    import numpy as np
+    import torch
     from oracle import scene_nerf as SN
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(0)
@@ -113,12 +159,113 @@ def cpu_baseline_scene(V, threads, n_pix=341, S=128, reps=3):
                       f'dropped), median {t:.3f} s'}
 
 
+def cpu_baseline_psnr(dev, steps=150, G=24, HW=32, V=3, n_rand=256, seed=0, threads=None):
+    """PSNR parity (BASELINE.json metric, second half): the oracle trainer (CPU) and the HIP engine start from ONE
+    initialisation and see the same ray indices and jitter at every step; a smooth "teacher" scene rendered by the HIP
+    forward provides learnable 32x32 views.  Rays are drawn from 75 % of the pixels; PSNR (lib/utils.py mse2psnr =
+    -10 log10 mse, as printed at lib/recon_scene.py:654-685) of both models is taken on the 25 % held-out pixels, rendered
+    by each model's own training forward without jitter.  The HIP engine is the thing under test, the oracle the checker."""
+    import numpy as np
+    import torch
+    from oracle import voxurf_oracle as O
+    from poseprobe_amd import ops
+    from poseprobe_amd import synthetic as syn
+    from poseprobe_amd.engine import SceneConfig, TrainEngine
+    from poseprobe_amd.params_init import reference_like_params
+    if threads:
+        torch.set_num_threads(threads)
+    rs = syn.range_shape()
+    H = W = HW
+    Ks, w2c = syn.intrinsics(V, H, W), syn.cameras(V)
+    gs0 = 2000
+    cfg = SceneConfig(syn.XYZ_MIN, syn.XYZ_MAX, G ** 3, out_range=float(rs.max()))
+
+    def engine(pseed, se3, n):
+        e = TrainEngine(cfg, V, H, W, n, device=dev, pose_iters=3000)
+        e.set_views(np.zeros((V, H, W, 3), np.float32), np.ones((V, H, W, 1), np.float32), Ks, w2c)
+        P = reference_like_params(cfg, pseed)
+        # sdf_alpha 0.637: the mapped cube SDF has |gradient| ~ 1, so the eikonal prior agrees with the teacher's geometry
+        P['sdf_alpha'] = torch.tensor([0.637])
+        e.load_reference_params(P['k0'], P['sdf'], P['sdf_alpha'], P['sdf_beta'], P['rgbnet'], P['warp'], se3=torch.tensor(se3))
+        e.zero_grads()
+        return e, P
+
+    def render_all(e, step):
+        """Every pixel of every view through the engine's training forward (no jitter) -> [V*H*W, 3], cum_weights."""
+        n_px, N = V * H * W, e.N
+        out, acc = torch.zeros(n_px, 3, device=dev), torch.zeros(n_px, device=dev)
+        ws, sc = e.ws, e.cfg.pp
+        ops.pose_fwd(e.se3, e.w2c_init, e.refine_mask, e.w2c, e.c2w, e.jac)
+        for b in range(0, n_px, N):
+            idx = (torch.arange(b, b + N, device=dev) % n_px).int()
+            ops.raygen_select_fwd(sc, idx, e.c2w, e.intr, H, W, e.cfg.inverse_y, True, e.images, e.masks, ws.rays_o, ws.rays_d,
+                                  ws.viewdirs, ws.target, ws.mask_px)
+            e.core.sample(ws, torch.zeros(N, device=dev))
+            e._upload_step_scalars(step / e.cfg.N_iters)
+            inv_s = float(np.float32(1.0) / np.float32(e.cfg.s_val(step)))
+            F = e.flat
+            e.core.forward(ws, e.k0_cl, e.sdf, F.view('sdf_ab'), F.view('rgbnet'), F.view('warp'), inv_s, e.pe_w)
+            n = min(N, n_px - b)
+            out[b:b + n], acc[b:b + n] = ws.rgb_marched[:n], ws.cum_weights[:n]
+        torch.cuda.synchronize()
+        return out, acc
+
+    teacher, _ = engine(3, np.zeros((V, 6), np.float32), n_rand)
+    with torch.no_grad():                                          # a smooth colour field: low-frequency k0
+        X, Y, Z = cfg.world_size
+        gx, gy, gz = torch.meshgrid(torch.linspace(-1, 1, X, device=dev), torch.linspace(-1, 1, Y, device=dev),
+                                    torch.linspace(-1, 1, Z, device=dev), indexing='ij')
+        for c in range(12):
+            teacher.k0_cl[..., c] = 0.8 * torch.sin((c % 3 + 1) * gx + 0.5 * c) * torch.cos((c % 4) * gy) + 0.3 * gz
+    img, acc = render_all(teacher, gs0)
+    images = img.view(V, H, W, 3).cpu().numpy()
+    masks = (acc > 0.5).float().view(V, H, W, 1).cpu().numpy()
+    del teacher
+
+    se3_0 = syn.se3_perturbation(V, std=5e-3, seed=5)
+    student, P = engine(11 + seed, se3_0, n_rand)
+    student.set_views(images, masks, Ks, w2c)
+    scene = O.Scene(syn.XYZ_MIN, syn.XYZ_MAX, G ** 3, output_range=float(rs.max()), rect_size=rs.tolist())
+    st = O.TrainState(P, scene, torch.tensor(w2c), torch.tensor(Ks), torch.tensor(images), torch.tensor(masks),
+                      se3_refine=torch.tensor(se3_0), pose_iters=3000)
+    rng = np.random.RandomState(123 + seed)
+    n_px = V * H * W
+    perm = rng.permutation(n_px)
+    held, train = np.sort(perm[:n_px // 4]), perm[n_px // 4:]
+    t_cpu = 0.0
+    for s in range(steps):
+        idx = rng.choice(train, n_rand, replace=False).astype(np.int64)
+        jit = rng.rand(n_rand).astype(np.float32)
+        t0 = time.time()
+        st.step(torch.tensor(idx), torch.tensor(jit), gs0 + s)
+        t_cpu += time.time() - t0
+        student.train_step(torch.tensor(idx, dtype=torch.int32, device=dev), torch.tensor(jit, device=dev), gs0 + s)
+    torch.cuda.synchronize()
+    gs = gs0 + steps
+    target = torch.tensor(images).reshape(-1, 3)[held]
+    rgb_hip = render_all(student, gs)[0].cpu()[held]
+    with torch.no_grad():
+        c2w = O.pose_invert(O.current_pose_pnp(st.se3, torch.tensor(w2c)))
+    ro, rd, vd, _, _ = O.select_training_rays(torch.tensor(held), torch.tensor(images), torch.tensor(masks), torch.tensor(Ks), c2w)
+    rgb_cpu = O.voxurf_forward(st.P, scene, ro, rd, vd, jitter=None, global_step=gs)['rgb_marched'].detach()
+    psnr = lambda x: float(-10.0 * torch.log10(((x - target) ** 2).mean()))
+    p_hip, p_cpu = psnr(rgb_hip), psnr(rgb_cpu)
+    return {'psnr_hip': p_hip, 'psnr_oracle': p_cpu, 'abs_delta_db': abs(p_hip - p_cpu), 'tolerance_db': 0.1,
+            'within_tolerance': bool(abs(p_hip - p_cpu) <= 0.1), 'steps': steps, 'oracle_s_per_step': t_cpu / max(steps, 1),
+            'pixel_max_abs_diff': float((rgb_hip - rgb_cpu).abs().max()),
+            'workload': f'{G}^3 grid, {V} teacher-rendered {H}x{W} views, N_rand={n_rand}, {steps} joint steps (grid + MLPs + poses) from '
+                        f'one initialisation with identical per-step rays and jitter; PSNR on the {len(held)} held-out pixels'}
+
+
+# ------------------------------------------------------------------------------------------------ dual-branch leg
 def dual_branch_leg(eng, idx_all, jit_all, gs, N, V, H, W, object_ms, dev, steps=20, warmup=3):
-    """Informative second measurement (never `value`): the same object-branch step plus the scene branch of the reference's
-    joint loop (lib/recon_scene.py:639-649): rand_rays // V pixels per view x 128 stratified samples through the 8 x 256
-    NeRF, 2 * huber loss, backward, Adam, poses shared through the object engine's pose Jacobian - first the coarse-only phase
-    (the first 30 % of the schedule), then the hierarchical phase (coarse + fine network on 128 + 128 samples)."""
-    from poseprobe_amd import bg_nerf
+    """BASELINE config 2 as the reference's joint loop runs it (lib/recon_scene.py:639-649): the same object-branch step
+    plus the scene branch - rand_rays // V pixels per view x 128 stratified samples through the 8 x 256 NeRF, 2 * huber loss,
+    backward, Adam, poses shared through the object engine's pose Jacobian - first the coarse-only phase (the first 30 % of
+    the schedule), then the hierarchical phase (coarse + fine network on 128 + 128 samples)."""
+    import numpy as np
+    import torch
+    from poseprobe_amd import _lib, bg_nerf, ops
     from poseprobe_amd.joint import DualBranchEngine
     opt = bg_nerf.default_options(sample_intvs=128)
     opt.nerf.fine_sampling, opt.nerf.sample_intvs_fine = True, 128
@@ -133,11 +280,24 @@ def dual_branch_leg(eng, idx_all, jit_all, gs, N, V, H, W, object_ms, dev, steps
     img = torch.rand(V, n_pix, 3, generator=g).to(dev)
     n_avail = idx_all.shape[0]
     fl_sample = 2 * (64 * 256 + 6 * 256 * 256 + 320 * 256 + 256 + 288 * 128 + 128 * 3)       # forward FLOP per sample
+    split = _lib.get_option('nerf_split') == 1
     out = {'workload': f'object-branch step + scene branch: {V} x {n_pix} rays, 8x256 NeRF (BARF PE), 2*huber loss, backward, '
                        f'Adam; shared poses, loss = 0.1 L_obj + L_bg; coarse phase = {S} stratified samples, hierarchical '
                        f'phase = coarse + fine network on {S}+{S} samples', 'object_rays': N, 'scene_rays': V * n_pix, 'n_gpus': 1,
-           'scene_arithmetic': 'fp32 operands and accumulation; forward / data-gradient products as 3 fp16 MFMA products (error vs '
-                               'fp64 equal to the fp32 MFMA path), weight-gradient products on fp32 MFMA; PP_NERF_SPLIT=0: fp32 MFMA only'}
+           'scene_arithmetic': ('fp32 operands and accumulation; matrix products as 3 fp16 MFMA products (error vs fp64 equal to '
+                                'the fp32 MFMA path)') if split else 'fp32 MFMA'}
+    # HIP events around the scene network's forward / backward chains (GEMMs + thin kernels), coarse phase only
+    ev = []
+
+    def timed(fn):
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*a, **k)
+            e1.record()
+            ev.append((e0, e1))
+        return wrapper
+
     for label, fine, samples in (('coarse_phase', False, V * n_pix * S), ('hierarchical_phase', True, V * n_pix * 3 * S)):
         for s in range(warmup):
             joint.train_step(idx_all[s % n_avail], jit_all[s % n_avail], gs + s, px[s], img, fine=fine)
@@ -150,15 +310,31 @@ def dual_branch_leg(eng, idx_all, jit_all, gs, N, V, H, W, object_ms, dev, steps
         scene_ms = ms - object_ms
         tf = 3 * fl_sample * samples / (scene_ms * 1e-3) / 1e12                                # fwd + data grad + weight grad
         out[label] = {'ms_per_step': ms, 'rays_per_s': (N + V * n_pix) / (ms * 1e-3), 'scene_samples': samples,
-                      'scene_ms': scene_ms, 'scene_algorithmic_tflops': tf,
-                      'scene_tflops_over_fp32_mfma_peak': tf / 157.3}      # informative: the products run as 3 fp16 MFMAs each
+                      'scene_ms': scene_ms, 'scene_algorithmic_tflops': tf}
+        if not fine:
+            orig = ops.nerf_fwd, ops.nerf_bwd
+            ops.nerf_fwd, ops.nerf_bwd = timed(ops.nerf_fwd), timed(ops.nerf_bwd)
+            for s in range(5):
+                joint.train_step(idx_all[s % n_avail], jit_all[s % n_avail], gs + s, px[s], img, fine=False)
+            torch.cuda.synchronize()
+            ops.nerf_fwd, ops.nerf_bwd = orig
+            chain_ms = float(np.sum([a.elapsed_time(b) for a, b in ev])) / 5
+            issued = (3 if split else 1) * 3 * fl_sample * samples           # matrix-pipe FLOPs actually issued
+            peak = FP16_MFMA_PEAK_TF if split else FP32_MFMA_PEAK_TF
+            out['roofline_scene'] = {
+                'bound': 'mfma', 'kernel': 'pp_nerf_fwd + pp_nerf_bwd: 9 forward, 10 data-gradient and 9 weight-gradient GEMMs of the '
+                                           '8x256 NeRF (+ encoding / head kernels, ~10 % of the time)',
+                'achieved': issued / (chain_ms * 1e-3) / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': issued / (chain_ms * 1e-3) / 1e12 / peak, 'traffic': None, 'ms_per_step': chain_ms,
+                'pipe': 'fp16 MFMA (3 products per fp32 product)' if split else 'fp32 MFMA',
+                'algorithmic_tflops': 3 * fl_sample * samples / (chain_ms * 1e-3) / 1e12}
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--grid', type=int, default=160)
     ap.add_argument('--n-rand', type=int, default=1024)
@@ -166,8 +342,19 @@ def main():
     ap.add_argument('--views', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
-    ap.add_argument('--no-dual', action='store_true', help='skip the informative dual-branch (object + scene) leg')
+    ap.add_argument('--no-dual', action='store_true', help='skip the dual-branch (object + scene) leg')
+    ap.add_argument('--no-psnr', action='store_true', help='skip the PSNR-parity leg (oracle vs HIP training run)')
+    ap.add_argument('--psnr-steps', type=int, default=150)
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves - before this process has touched the GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    import numpy as np
+    import torch
+    from poseprobe_amd import synthetic as syn
+    from poseprobe_amd.engine import SceneConfig, TrainEngine
 
     # stdout carries exactly ONE line (the JSON record).  Libraries that print to fd 1 (RCCL prints a version banner when
     # a communicator is created) are sent to stderr for the duration of the run.
@@ -178,6 +365,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run '
+                         f'--nproc-per-node {args.gpus}, or without RANK in the environment to let bench.py start the ranks)\n')
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dctx = None
@@ -189,7 +380,6 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         from poseprobe_amd.dist import DistContext
         dctx = DistContext()
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     G, H, W, V, N = args.grid, args.hw, args.hw, args.views, args.n_rand
     rs = syn.range_shape()
@@ -200,9 +390,11 @@ def main():
     init_engine_params(eng, cfg, seed=3)
     eng.zero_grads()
 
-    # every step's randomness is generated up front and is resident on the device: rank r takes its own ray shard
+    # every step's randomness (a prefix of a fresh permutation of all V*H*W pixels + per-ray jitter, as the reference draws
+    # per step at recon_scene.py:476,:598) is generated up front on the host and is resident on the device when the timed
+    # region starts; rank r takes its own ray shard
     total = args.steps + args.warmup
-    extra = min(10, args.steps)          # untimed post-pass that prices the MLP chains (second, informative roofline)
+    extra = min(10, args.steps)          # untimed post-pass that prices each MLP kernel separately (kernel table)
     idx_all, jit_all = [], []
     for s in range(total + extra):
         idx, jit = syn.step_randomness(V * H * W, N * world, seed=2000 + s)
@@ -216,38 +408,43 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # time the dominant kernel with HIP events on the launch stream (torch's current stream == our launch stream)
+    # HIP events on the launch stream (torch's current stream == the library's launch stream) around the two candidates for
+    # the longest kernel of the step, INSIDE the timed region: the fused grid pass and the warp MLP's data-gradient kernel
     from poseprobe_amd import ops
-    ev = []
-    def timed_grid_step(fn):
+    events = {}
+
+    def timed(name, fn):
         def wrapper(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             fn(*a, **k)
             e1.record()
-            ev.append((e0, e1))
+            events.setdefault(name, []).append((e0, e1))
         return wrapper
 
-    ops.grid_tv_adam_step = timed_grid_step(ops.grid_tv_adam_step)                   # dense pass (ZeRO-1 slabs)
-    ops.grid_tv_adam_step_sparse = timed_grid_step(ops.grid_tv_adam_step_sparse)     # same kernel with the touched-voxel map
-    # second roofline: the two MLPs on the matrix cores (fp32 MFMA).  Every event pair drains the launch pipeline, so
-    # these four extra pairs per step are taken in a short pass AFTER the timed region, not inside it.
-    mlp_ev = []
+    def staged_warp_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad, ctx=None):
+        """pp_warp_bwd as its two stages (identical work: pp_warp_bwd == data then weights), so that each kernel gets its
+        own event pair."""
+        ops.warp_bwd_data(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad)
+        ops.warp_bwd_weights(acts, scratch, count, capacity, params_grad)
 
-    def timed(fn):
-        def wrapper(*a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            fn(*a, **k)
-            e1.record()
-            mlp_ev.append((e0, e1))
-        return wrapper
+    def staged_rgbnet_bwd(params, feat, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad, ctx=None):
+        ops.rgbnet_bwd_data(params, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad)
+        ops.rgbnet_bwd_weights(feat, acts, scratch, count, capacity, params_grad)
+
+    originals = {n: getattr(ops, n) for n in ('grid_tv_adam_step', 'grid_tv_adam_step_sparse', 'warp_bwd_data', 'warp_bwd',
+                                              'rgbnet_bwd', 'warp_fwd', 'rgbnet_fwd', 'warp_bwd_weights', 'rgbnet_bwd_data',
+                                              'rgbnet_bwd_weights')}
+    ops.grid_tv_adam_step = timed('k_grid_tv_adam', ops.grid_tv_adam_step)                   # dense pass (ZeRO-1 slabs)
+    ops.grid_tv_adam_step_sparse = timed('k_grid_tv_adam', ops.grid_tv_adam_step_sparse)     # same kernel, touched-voxel map
+    ops.warp_bwd_data = timed('k_warp_fused_bwd', ops.warp_bwd_data)
+    ops.warp_bwd = staged_warp_bwd
 
     gs = 10
     for s in range(args.warmup):
         eng.train_step(idx_all[s], jit_all[s], gs + s)
     barrier()
-    ev.clear()
+    events.clear()
     t0 = time.perf_counter()
     for s in range(args.warmup, total):
         eng.train_step(idx_all[s], jit_all[s], gs + s)
@@ -258,60 +455,99 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     M = int(eng.ws.count.item())
-    mlp_names = ('warp_fwd', 'warp_bwd', 'rgbnet_fwd', 'rgbnet_bwd')
-    mlp_orig = {n: getattr(ops, n) for n in mlp_names}
-    for n in mlp_names:
-        setattr(ops, n, timed(mlp_orig[n]))
-    n_ev = len(ev)
+    mean_ms = lambda name: float(np.mean([a.elapsed_time(b) for a, b in events[name]])) if events.get(name) else float('nan')
+    grid_ms, warp_bwd_ms = mean_ms('k_grid_tv_adam'), mean_ms('k_warp_fused_bwd')
+    exchange_rows = None if dctx is None else dctx.rows
+
+    # post-pass (untimed): every MLP kernel on its own event pair -> kernel table and the MLP-chain roofline
+    events.clear()
+    for n in ('grid_tv_adam_step', 'grid_tv_adam_step_sparse'):
+        setattr(ops, n, originals[n])
+    ops.warp_fwd = timed('k_warp_fused_fwd', originals['warp_fwd'])
+    ops.rgbnet_fwd = timed('k_rgb_fused_fwd', originals['rgbnet_fwd'])
+    ops.warp_bwd_weights = timed('k_wgrad_chain<128> (warp)', originals['warp_bwd_weights'])
+    ops.rgbnet_bwd_data = timed('k_rgb_fused_bwd', originals['rgbnet_bwd_data'])
+    ops.rgbnet_bwd_weights = timed('k_wgrad_chain<64> (rgbnet)', originals['rgbnet_bwd_weights'])
+    ops.rgbnet_bwd = staged_rgbnet_bwd
     for s in range(total, total + extra):
         eng.train_step(idx_all[s], jit_all[s], gs + s)
     barrier()
-    for n in mlp_names:
-        setattr(ops, n, mlp_orig[n])
-    del ev[n_ev:]                                    # the grid kernel is priced over the timed region only
-    grid_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float('nan')
+    Mx = int(eng.ws.count.item())
+    for n, f in originals.items():
+        setattr(ops, n, f)
+    hidden = 2 * 128 * 128
+    flops = {'k_warp_fused_fwd': 3 * 4 * hidden, 'k_warp_fused_bwd': 3 * 4 * hidden, 'k_wgrad_chain<128> (warp)': 3 * 4 * hidden,
+             'k_rgb_fused_fwd': 2 * (64 * 128 + 2 * 128 * 128), 'k_rgb_fused_bwd': 2 * (64 * 128 + 2 * 128 * 128),
+             'k_wgrad_chain<64> (rgbnet)': 2 * (64 * 128 + 2 * 128 * 128)}          # MFMA-shaped FLOP per sample
+    kernels = {}
+    for name, fl in flops.items():
+        ms = mean_ms(name)
+        kernels[name] = {'ms': ms, 'tflops': fl * Mx / (ms * 1e-3) / 1e12, 'frac_of_fp32_mfma_peak': fl * Mx / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF}
+    mlp_ms = float(np.sum([k['ms'] for k in kernels.values()]))
+    flop_per_sample = sum(flops.values())
+    mlp_tflops = flop_per_sample * Mx / (mlp_ms * 1e-3) / 1e12
+
     xb, xe = eng.x_slab
     X, Y, Z = cfg.world_size
-    # algorithmic bytes of the pass: p, m, v read + p', m, v written for every voxel (288 B at C=12), the gradient read
+    # algorithmic bytes of the grid pass: p, m, v read + p', m, v written for every voxel (288 B at C=12), the gradient read
     # + re-zeroed only for the voxels the scatter marked (96 B x marked fraction; fraction = 1 for the dense pass)
     marked = 1.0
     if (xb, xe) == (0, X) and not (dctx is not None and dctx.local_scatter):
         marked = float(eng.k0_touched[1 - eng.touch_par].ne(0).sum().item()) / (X * Y * Z)   # the map the last step consumed
     per_voxel = GRID_BYTES_PER_VOXEL * (0.75 + 0.25 * marked)
     grid_bytes = per_voxel * (xe - xb) * Y * Z
-    achieved = grid_bytes / (grid_ms * 1e-3) / 1e9
-    # MFMA-shaped work per sample: warp hidden GEMMs 3 layers x 4 rows x 2*128*128 x (fwd + 2 bwd),
-    # rgbnet (64*128 + 2*128*128) x 2 x (fwd + 2 bwd)
-    flop_per_sample = 3 * (3 * 4 * 2 * 128 * 128) + 3 * (2 * (64 * 128 + 2 * 128 * 128))
-    mlp_ms = float(np.sum([a.elapsed_time(b) for a, b in mlp_ev])) / max(extra, 1) if mlp_ev else float('nan')
-    mlp_tflops = flop_per_sample * M / (mlp_ms * 1e-3) / 1e12
+    grid_gbs = grid_bytes / (grid_ms * 1e-3) / 1e9
+    roofline_grid = {'bound': 'hbm', 'kernel': 'k_grid_tv_adam (fused TV-grad + Adam + zero-grad over k0, gradient touched only where the scatter marked)',
+                     'achieved': grid_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': grid_gbs / HBM_PEAK_GBS,
+                     'traffic': pmc_traffic(G, (xe - xb) * Y * Z, marked < 1.0), 'traffic_source': 'committed rocprofv3 PMC pass (profiles/), not this run',
+                     'ms_per_launch': grid_ms, 'algorithmic_bytes_per_launch': grid_bytes, 'grad_voxels_marked': marked}
+    wb_tf = flops['k_warp_fused_bwd'] * M / (warp_bwd_ms * 1e-3) / 1e12
+    roofline_warp_bwd = {'bound': 'mfma', 'kernel': 'k_warp_fused_bwd (warp MLP data-gradient chain: 3 hidden layers x 4 rows per sample, fp32 MFMA 32x32x2; '
+                                                    'thin layers + bias gradients in the same kernel)',
+                         'achieved': wb_tf, 'peak': FP32_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': wb_tf / FP32_MFMA_PEAK_TF, 'traffic': None,
+                         'ms_per_launch': warp_bwd_ms, 'algorithmic_flops_per_launch': flops['k_warp_fused_bwd'] * M,
+                         'flop_per_sample': flops['k_warp_fused_bwd'], 'samples': M}
+    dominant = roofline_warp_bwd if warp_bwd_ms >= grid_ms else roofline_grid
 
     dual = None
     if world == 1 and not args.no_dual:
         dual = dual_branch_leg(eng, idx_all, jit_all, gs, N, V, H, W, dt / args.steps * 1e3, dev)
 
     if rank == 0:
+        if world > 1:
+            par = (f'ray-sharded dp{world}, k0 gradient exchanged per sample (all-gather of {exchange_rows} rows x 64 B per rank), replicated grid optimiser'
+                   if dctx.mode == 'samples' else f'ray-sharded dp{world}, dense reduce-scatter + ZeRO-1 grid optimiser')
+        else:
+            par = 'single GPU'
         out = {
             'metric': 'rays_per_sec_train_step', 'value': N * world * args.steps / dt, 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'DTU-scan1-like {V}-view {H}x{W}, object-branch train step (ray select, render, '
                                    f'losses, backward, TV+Adam), {G}^3 grid, {cfg.n_samples} samples/ray, '
-                                   f'N_rand={N}/GPU', 'grid': G, 'n_rand_per_gpu': N, 'samples_in_bbox_last_step': M,
-                       'parallelism': (f'ray-sharded dp{world}, k0 gradient exchanged per sample (all-gather), replicated grid optimiser' if (dctx is None or dctx.mode == 'samples') else f'ray-sharded dp{world}, dense reduce-scatter + ZeRO-1 grid optimiser') if world > 1 else 'single GPU'},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_grid_tv_adam (fused TV-grad + Adam + zero-grad over k0, gradient touched only where the scatter marked)',
-                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': pmc_traffic(G, (xe - xb) * Y * Z, marked < 1.0), 'ms_per_launch': grid_ms, 'algorithmic_bytes_per_launch': grid_bytes,
-                         'grad_voxels_marked': marked},
-            'roofline_mfma': {'bound': 'mfma', 'kernel': 'warp + rgbnet MLP chains (layer-fused fwd / bwd-data / weight-gradient kernels, fp32 MFMA 32x32x2)',
-                              'achieved': mlp_tflops, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': mlp_tflops / 157.3,
-                              'ms_per_step': mlp_ms, 'flop_per_sample': flop_per_sample},
+                                   f'N_rand={N}/GPU; per-step ray permutation + jitter pre-generated on the host and resident '
+                                   f'in HBM (the reference draws randperm inside the step)', 'grid': G, 'n_rand_per_gpu': N,
+                       'samples_in_bbox_last_step': M, 'parallelism': par},
+            'roofline': dominant, 'roofline_grid': roofline_grid,
+            'roofline_mlp': {'bound': 'mfma', 'kernel': 'warp + rgbnet MLP chains (6 layer-fused kernels: fwd / bwd-data / weight-gradient, fp32 MFMA 32x32x2)',
+                             'achieved': mlp_tflops, 'peak': FP32_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': mlp_tflops / FP32_MFMA_PEAK_TF,
+                             'traffic': None, 'ms_per_step': mlp_ms, 'flop_per_sample': flop_per_sample, 'kernels': kernels,
+                             'measured': f'untimed post-pass of {extra} steps, one HIP event pair per kernel'},
         }
         out['dual_branch'] = dual
+        if dual is not None:
+            out['dual_branch_rays_per_s'] = dual['coarse_phase']['rays_per_s']
+            out['dual_branch_ms_per_step'] = dual['coarse_phase']['ms_per_step']
+            out['dual_branch_hierarchical_rays_per_s'] = dual['hierarchical_phase']['rays_per_s']
+            out['roofline_scene'] = dual.pop('roofline_scene', None)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(G, H, W, V, N, views, args.cpu_budget)
         else:
             out['cpu_baseline'] = None
+        if world == 1 and not args.no_psnr:
+            out['psnr_parity'] = cpu_baseline_psnr(dev, steps=args.psnr_steps, threads=min(32, torch.get_num_threads()))
+        else:
+            out['psnr_parity'] = None
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if use_dist:

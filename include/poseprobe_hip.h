@@ -36,6 +36,14 @@ typedef enum {
 const char* pp_last_error(void);
 int pp_abi_version(void);
 
+/* Tuning options: explicit, caller-set, process-wide integers with compiled-in defaults (the measured best on MI355X).
+ * The library never reads the environment; the Python host maps PP_* environment variables onto these calls when it
+ * loads the library (poseprobe_amd/_lib.py).  Names: mlp_fused, wgrad_split, grid_chunks, nerf_split, nerf_split_tn,
+ * nerf_bitmask, nerf_gemm_wgs, nerf_tn_ch, nerf_tn_split_wgs, nerf_tn_wgs, nerf_bn, nerf_planes (meaning and ranges:
+ * csrc/pp_common.h, csrc/pp_error.hip).  Thread-safe (atomic); unknown names / out-of-range values are refused. */
+int pp_set_option(const char* name, int32_t value);
+int pp_get_option(const char* name, int32_t* value);
+
 /* Static description of the voxel scene; mirrors the attributes Voxurf derives in __init__ /
  * _set_grid_resolution (lib/voxurf_coarse.py:67-68, :319-323) and the render_kwargs
  * (lib/recon_scene.py:208-217). */
@@ -90,7 +98,10 @@ int pp_raygen_select_bwd(const pp_scene* sc, const int32_t* ray_idx, int32_t n_r
  * jitter[N] may be NULL (eval).  Outputs: t_min,t_max[N], ray_start[N+1] (exclusive prefix of the
  * per-ray in-bbox counts; ray_start[N] = M, also written to count[0]), pts[M,3], ray_id[M],
  * step_k[M] (sample index within the ray), step[M] (= stepsize*voxel_size*(k+jitter)),
- * mask_keep[N*S] (uint8, 1 = in bbox; may be NULL).  capacity = allocated rows of the per-sample outputs. */
+ * mask_keep[N*S] (uint8, 1 = in bbox; may be NULL).  capacity = allocated rows of the per-sample outputs: when the in-bbox
+ * total exceeds it, count[0] = ray_start[N] = capacity and every ray_start entry is clamped to it (rays past the capacity
+ * become empty, the ray that straddles it is cut), so no consumer of ray_start ever indexes past the allocation;
+ * count[0] == capacity is the caller's truncation signal.  The same holds for pp_sample_var. */
 int pp_sample_dense(const pp_scene* sc, const float* rays_o, const float* rays_d, const float* jitter,
                     int32_t n_rays, int32_t capacity, float* t_min, float* t_max, int32_t* ray_start,
                     int32_t* count, float* pts, int32_t* ray_id, int32_t* step_k, float* step,
@@ -157,7 +168,8 @@ int pp_geometry_bwd_priors(const pp_scene* sc, const float* sdf_grid, const floa
                            const float* warp_out, const float* viewdirs, const int32_t* ray_id, const int32_t* count,
                            int32_t capacity, float inv_s, const float* g_alpha, const float* g_gradient, float w_eikonal,
                            float w_deform, float loss_scale, int32_t accumulate, float* warp_out_grad, float* pts_grad,
-                           float* viewdir_grad_s, float* sdf_ab_grad, float* loss_out, void* stream);
+                           float* viewdir_grad_s, float* sdf_ab_grad, float* loss_out, const float* batch_norm,
+                           void* stream);
 
 /* ---------------------------------------------------------------- multi-GPU: k0 gradient exchange at sample granularity
  * (no counterpart in the reference, which has no distributed path; replaces a dense 196 MB reduce-scatter by an
@@ -224,22 +236,43 @@ int pp_warp_bwd(const float* params, const float* pts, const float* acts, const 
                 float* params_grad /*atomic +=*/, float* pts_grad /* += */, void* ctx /*pp_context or NULL*/,
                 void* stream);
 
+/* Two-stage forms of the two backward chains above (layer-fused kernels only; option mlp_fused = 0 returns
+ * PP_ERR_UNSUPPORTED): stage 1 = data gradients + thin-layer and bias gradients, leaves the hidden layers' output gradients
+ * in `scratch`; stage 2 = the hidden layers' weight gradients from `scratch` and the stored activations.
+ * pp_warp_bwd == pp_warp_bwd_data then pp_warp_bwd_weights (same for rgbnet); the split lets a caller time the kernels
+ * separately, interleave other work, or put stage 2 on another stream. */
+int pp_warp_bwd_data(const float* params, const float* pts, const float* acts, const float* out_grad,
+                     const int32_t* count, int32_t capacity, float out_range, float* scratch, float* params_grad,
+                     float* pts_grad, void* stream);
+int pp_warp_bwd_weights(const float* acts, const float* scratch, const int32_t* count, int32_t capacity,
+                        float* params_grad, void* stream);
+int pp_rgbnet_bwd_data(const float* params, const float* acts, const float* rgb, const float* rgb_grad,
+                       const int32_t* count, int32_t capacity, float* scratch, float* params_grad, float* feat_grad,
+                       void* stream);
+int pp_rgbnet_bwd_weights(const float* feat, const float* acts, const float* scratch, const int32_t* count,
+                          int32_t capacity, float* params_grad, void* stream);
+
 /* ---------------------------------------------------------------- losses: lib/losses.py:6-74 (object_losses),
  * forward values + gradients w.r.t. the render outputs in one pass.  loss_scale multiplies every gradient
  * (recon_scene.py:648 scales the object loss by 0.1).
  * loss_out[8] (atomic +=, caller zeroes): [0] mse, [1] entropy, [2] eikonal, [3] grad_deform, [4] sdf_correct,
  * [5] sdf_deform, [6] bce mask, [7] unused (unweighted scalars, as loss_scalars in the reference).
- * mask_sum[1] is device scratch.  g_rgb_marched is w.r.t. the CLAMPED rgb_marched (pp_march_bwd applies the
- * clamp mask). */
+ * mask_sum[1] receives the batch's masked-pixel count.  g_rgb_marched is w.r.t. the CLAMPED rgb_marched
+ * (pp_march_bwd applies the clamp mask).
+ * batch_norm (device float[2], may be NULL): ray-sharded data parallelism.  The reference normalises the masked MSE by
+ * the batch's masked-pixel count and the sample-level priors by the batch's sample count (lib/losses.py:6-29); with the
+ * rays of ONE batch spread over W ranks and gradients averaged over ranks, batch_norm[0] = (sum over ranks of the
+ * masked-pixel counts) / W and batch_norm[1] = (sum over ranks of the sample counts) / W make the sharded step equal the
+ * union-batch step.  NULL = this call's own counts (single GPU). */
 int pp_loss_rays(const float* rgb_marched, const float* alphainv_last, const float* cum_weights,
                  const float* target, const float* mask_px, float* mask_sum, int32_t n_rays, float w_main,
                  float w_entropy, float w_mask, float loss_scale, float* g_rgb_marched, float* g_alphainv_last,
-                 float* g_cum_weights, float* loss_out, void* stream);
+                 float* g_cum_weights, float* loss_out, const float* batch_norm, void* stream);
 /* g_gradient[M,3] is ACCUMULATED (+=); g_grad_deform[M,9], g_correction[M], g_sdf_deform[M] are written. */
 int pp_loss_samples(const float* gradient, const float* grad_deform, const float* warp_out,
                     const float* sdf_deform, const int32_t* count, int32_t capacity, float w_eikonal,
                     float w_deform, float loss_scale, float* g_gradient, float* g_grad_deform,
-                    float* g_correction, float* g_sdf_deform, float* loss_out, void* stream);
+                    float* g_correction, float* g_sdf_deform, float* loss_out, const float* batch_norm, void* stream);
 
 /* ---------------------------------------------------------------- optimiser: lib/utils.py:82-198 (Adam, betas
  * (0.9,0.99)) fused with the k0 total-variation gradient (voxurf_coarse.py:443-456, :1298-1313; weight

@@ -33,6 +33,8 @@ def parse_header(path=HEADER):
             argname = re.findall(r'(\w+)$', a)[0]
             if 'pp_scene' in a:
                 ct = ctypes.POINTER(pp_scene)
+            elif 'char*' in a.replace(' *', '*'):
+                ct = ctypes.c_char_p
             elif '*' in a:
                 ct = ctypes.c_void_p
             elif 'uint8_t' in a and '*' not in a:
@@ -71,7 +73,31 @@ def lib():
         fn.restype = ctypes.c_int
         fn.argtypes = [ct for ct, _ in args]
     _lib = L
+    _options_from_environment(L)
     return L
+
+
+# PP_<NAME>=<int> in the environment of the HOST process is applied once, right after loading, through pp_set_option: the
+# switches are the host's, the library itself has no hidden state read from the environment.
+OPTION_NAMES = ('mlp_fused', 'wgrad_split', 'grid_chunks', 'nerf_split', 'nerf_split_tn', 'nerf_bitmask', 'nerf_gemm_wgs',
+                'nerf_tn_ch', 'nerf_tn_split_wgs', 'nerf_tn_wgs', 'nerf_bn', 'nerf_planes')
+
+
+def _options_from_environment(L):
+    for name in OPTION_NAMES:
+        v = os.environ.get('PP_' + name.upper())
+        if v not in (None, ''):
+            check(L.pp_set_option(name.encode(), int(v)), 'pp_set_option')
+
+
+def set_option(name, value):
+    check(lib().pp_set_option(name.encode(), int(value)), 'pp_set_option')
+
+
+def get_option(name):
+    v = ctypes.c_int32()
+    check(lib().pp_get_option(name.encode(), ctypes.byref(v)), 'pp_get_option')
+    return v.value
 
 
 def check(status, name):

@@ -94,15 +94,28 @@ class _LinearParams(torch.nn.Module):
 
 
 class _Workspace:
+    """Per-shape buffers that no pending backward depends on: the backward pass's scratch (used only inside one pp_nerf_bwd
+    call), the device-side sample count, and an activation block for passes that nobody will differentiate through autograd
+    (no_grad forwards, SceneEngine's own forward / backward pairs).  A forward pass that autograd may differentiate owns its
+    activation block (see _NerfSamples): any number of them may be pending at the same shape, as in the reference."""
+
     def __init__(self, R, S, dev):
         M = R * S
-        a, s = ops.nerf_workspace(M, R)
+        self.acts_floats, s = ops.nerf_workspace(M, R)
         f = dict(dtype=torch.float32, device=dev)
-        self.R, self.S = R, S
-        self.acts = torch.empty(a, **f)
+        self.R, self.S, self.dev = R, S, dev
+        self._acts = None
         self.scratch = torch.zeros(s, **f)
         self.count = torch.tensor([M], dtype=torch.int32, device=dev)
-        self.generation = 0          # bumped by every forward pass that overwrites `acts`
+
+    @property
+    def acts(self):
+        if self._acts is None:
+            self._acts = torch.empty(self.acts_floats, dtype=torch.float32, device=self.dev)
+        return self._acts
+
+    def new_acts(self):
+        return torch.empty(self.acts_floats, dtype=torch.float32, device=self.dev)
 
 
 class _NerfSamples(torch.autograd.Function):
@@ -115,24 +128,25 @@ class _NerfSamples(torch.autograd.Function):
         f = dict(dtype=torch.float32, device=depth.device)
         center, ray, depth = center.contiguous().float(), ray.contiguous().float(), depth.contiguous().float()
         rgb_s, dens = torch.empty(R * S, 3, **f), torch.empty(R * S, **f)
-        ops.nerf_fwd(net.flat, center, ray, depth, net.band_weights(), ws.count, R, S, ws.acts, rgb_s, dens)
-        ctx.net, ctx.ws, ctx.generation = net, ws, ws.generation
+        # a pass that may be differentiated keeps its own activations until its backward has run (the caching allocator
+        # recycles the block afterwards); anything else shares the per-shape block
+        acts = ws.new_acts() if any(ctx.needs_input_grad) else ws.acts
+        ops.nerf_fwd(net.flat, center, ray, depth, net.band_weights(), ws.count, R, S, acts, rgb_s, dens)
+        ctx.net, ctx.ws, ctx.acts = net, ws, acts
         ctx.save_for_backward(ray, depth, rgb_s)
         return rgb_s, dens
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_rgb_s, g_dens):
-        net, ws = ctx.net, ctx.ws
+        net, ws, acts = ctx.net, ctx.ws, ctx.acts
         ray, depth, rgb_s = ctx.saved_tensors
-        if ws.generation != ctx.generation:
-            raise RuntimeError('bg_nerf: the activations of this forward pass were overwritten by a later forward pass of the '
-                               'same shape; run backward first (or use a second NeRF instance, as coarse / fine do)')
+        ctx.acts = None                                            # once_differentiable: the block is free after this call
         R, S = depth.shape
         f = dict(dtype=torch.float32, device=depth.device)
         pgrad = torch.zeros_like(net.flat)
         g_center, g_ray = torch.empty(R, 3, **f), torch.empty(R, 3, **f)
-        ops.nerf_bwd(net.flat, ray, depth, ws.count, R, S, ws.acts, rgb_s, g_rgb_s.contiguous().float(),
+        ops.nerf_bwd(net.flat, ray, depth, ws.count, R, S, acts, rgb_s, g_rgb_s.contiguous().float(),
                      g_dens.contiguous().float(), ws.scratch, pgrad, g_center, g_ray)
         return (None, g_center, g_ray, None, *net._views(pgrad))
 
@@ -268,7 +282,6 @@ class NeRF(torch.nn.Module):
             if len(self._ws) >= 4:
                 self._ws.clear()
             ws = self._ws[(R, S)] = _Workspace(R, S, self.flat.device)
-        ws.generation += 1
         return ws
 
     def _params(self):

@@ -1,36 +1,71 @@
 """Builds libposeprobe_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
     python -m poseprobe_amd.build_ext [--force]
+
+One object per .hip source (csrc/_obj/*.o, compiled in parallel, rebuilt when the source or ANY header / generated
+include of csrc/ or the public header is newer), then one link step.
 """
 import glob
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, '_obj')
 OUT = os.path.join(HERE, 'libposeprobe_hip.so')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-Wno-pass-failed',
-         '-Wno-unused-result', '-Wno-unused-value']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-Wno-pass-failed', '-Wno-unused-result',
+         '-Wno-unused-value']
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
+def headers():
+    """Everything a translation unit may include: csrc/*.h, generated csrc/*.inc, the public C header."""
+    return (glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inc'))
+            + [os.path.join(HERE, '..', 'include', 'poseprobe_hip.h')])
+
+
+def _obj(src):
+    return os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
+
+
+def stale_sources():
+    newest_header = max(os.path.getmtime(h) for h in headers())
+    out = []
+    for s in sources():
+        o = _obj(s)
+        if not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), newest_header):
+            out.append(s)
+    return out
+
+
 def is_stale():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or stale_sources():
         return True
-    t = os.path.getmtime(OUT)
-    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(HERE, '..', 'include', 'poseprobe_hip.h')]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(_obj(s)) > os.path.getmtime(OUT) for s in sources())
 
 
 def build(force=False, verbose=True):
     if not force and not is_stale():
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + os.environ.get('PP_EXTRA_HIPCC_FLAGS', '').split() + sources() + ['-o', OUT]
+    extra = os.environ.get('PP_EXTRA_HIPCC_FLAGS', '').split()
+    os.makedirs(OBJ, exist_ok=True)
+    todo = sources() if force else stale_sources()
+
+    def compile_one(src):
+        cmd = [hipcc] + FLAGS + extra + ['-c', src, '-o', _obj(src)]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(todo)))) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + [_obj(s) for s in sources()] + ['-o', OUT]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

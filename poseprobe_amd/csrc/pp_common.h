@@ -11,6 +11,25 @@
 
 void pp_set_error(const char* fmt, ...);
 
+// Tuning options (include/poseprobe_hip.h: pp_set_option / pp_get_option).  Explicit caller-set values with compiled-in
+// defaults; the library never reads the environment.
+enum PPOption {
+  PP_OPT_MLP_FUSED = 0,        // 1: layer-fused object-branch MLP kernels, 0: layer-by-layer GEMMs (A/B runs)
+  PP_OPT_WGRAD_SPLIT,          // 1: split-precision weight-gradient kernels in the object branch (measured slower)
+  PP_OPT_GRID_CHUNKS,          // x-chunks of the fused TV + Adam pass (0 = heuristic)
+  PP_OPT_NERF_SPLIT,           // scene branch: NT products as three fp16 products (1) or on the fp32 instructions (0)
+  PP_OPT_NERF_SPLIT_TN,        // scene branch: weight-gradient products likewise
+  PP_OPT_NERF_BITMASK,         // scene branch: one-bit ReLU masks
+  PP_OPT_NERF_GEMM_WGS,        // scene branch: persistent work-groups per column block
+  PP_OPT_NERF_TN_CH,           // scene branch: rows per LDS chunk of the fp32 weight-gradient GEMM (32 | 64)
+  PP_OPT_NERF_TN_SPLIT_WGS,    // scene branch: row splits of the split-precision weight-gradient kernel
+  PP_OPT_NERF_TN_WGS,          // scene branch: row splits of the fp32 weight-gradient kernel
+  PP_OPT_NERF_BN,              // scene branch: 256 selects the 128 x 256 tile of the fp32 NT GEMM
+  PP_OPT_NERF_PLANES,          // scene branch: 1 = activations travel as pre-split fp16 hi / lo planes (pp_gemm_planes.h)
+  PP_OPT_COUNT
+};
+int pp_opt(int id);
+
 #define PP_REQUIRE(cond, msg)                                     \
   do {                                                            \
     if (!(cond)) {                                                \

@@ -168,13 +168,15 @@ __global__ __launch_bounds__(256) void k_geometry_bwd(
     const float* __restrict__ g_gradient, const float* __restrict__ g_sdf_final, const float* __restrict__ g_sdf_deform,
     const float* __restrict__ g_grad_deform, const float* __restrict__ g_correction, int accumulate,
     float* __restrict__ warp_out_grad, float* __restrict__ pts_grad, float* __restrict__ vgrad_s,
-    float* __restrict__ sdf_ab_grad, float w_eik, float w_dyn, float ls, float* __restrict__ loss_out) {
+    float* __restrict__ sdf_ab_grad, float w_eik, float w_dyn, float ls, float* __restrict__ loss_out,
+    const float* __restrict__ batch_norm) {
   __shared__ float red[6][4];
   int m = blockIdx.x * blockDim.x + threadIdx.x;
   int M = min(count[0], capacity);
   float ga_sum = 0.f, gb_sum = 0.f;
   float l_eik = 0.f, l_gd = 0.f, l_c = 0.f, l_sd = 0.f;
-  const float invM = M > 0 ? 1.f / (float)M : 0.f;
+  float invM = M > 0 ? 1.f / (float)M : 0.f;
+  if (PRIORS && batch_norm) invM = batch_norm[1] > 0.f ? 1.f / batch_norm[1] : 0.f;   // union batch's sample count / world size
   if (m < M) {
     MapAB mp = map_ab(sdf_ab);
     float p[3] = {pts[m * 3], pts[m * 3 + 1], pts[m * 3 + 2]};
@@ -327,7 +329,7 @@ extern "C" int pp_geometry_bwd(const pp_scene* sc, const float* sdf_grid, const 
   hipLaunchKernelGGL(k_geometry_bwd<false>, dim3(pp_div_up(capacity, 256)), dim3(256), 0, pp_stream(stream), pp_scene_dev(sc),
                      sdf_grid, sdf_ab, pts, warp_out, viewdirs, ray_id, count, capacity, inv_s, g_alpha, g_gradient,
                      g_sdf_final, g_sdf_deform, g_grad_deform, g_correction, accumulate, warp_out_grad, pts_grad,
-                     viewdir_grad_s, sdf_ab_grad, 0.f, 0.f, 0.f, (float*)nullptr);
+                     viewdir_grad_s, sdf_ab_grad, 0.f, 0.f, 0.f, (float*)nullptr, (const float*)nullptr);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }
@@ -337,14 +339,14 @@ extern "C" int pp_geometry_bwd_priors(const pp_scene* sc, const float* sdf_grid,
                                       const int32_t* count, int32_t capacity, float inv_s, const float* g_alpha,
                                       const float* g_gradient, float w_eikonal, float w_deform, float loss_scale,
                                       int32_t accumulate, float* warp_out_grad, float* pts_grad, float* viewdir_grad_s,
-                                      float* sdf_ab_grad, float* loss_out, void* stream) {
+                                      float* sdf_ab_grad, float* loss_out, const float* batch_norm, void* stream) {
   PP_REQUIRE(sc && sdf_grid && sdf_ab && pts && warp_out && viewdirs && ray_id && count && warp_out_grad && pts_grad,
              "null pointer");
   PP_REQUIRE(capacity > 0, "capacity<=0");
   hipLaunchKernelGGL(k_geometry_bwd<true>, dim3(pp_div_up(capacity, 256)), dim3(256), 0, pp_stream(stream), pp_scene_dev(sc),
                      sdf_grid, sdf_ab, pts, warp_out, viewdirs, ray_id, count, capacity, inv_s, g_alpha, g_gradient,
                      nullptr, nullptr, nullptr, nullptr, accumulate, warp_out_grad, pts_grad, viewdir_grad_s, sdf_ab_grad,
-                     w_eikonal, w_deform, loss_scale, loss_out);
+                     w_eikonal, w_deform, loss_scale, loss_out, batch_norm);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }

@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void k_loss_rays(const float* __restrict__ rgb
                                                    const float* __restrict__ mask_px, float* __restrict__ mask_sum,
                                                    int n_rays, float w_main, float w_ent, float w_mask, float ls,
                                                    float* __restrict__ g_rgbm, float* __restrict__ g_alast,
-                                                   float* __restrict__ g_cw, float* __restrict__ loss_out) {
+                                                   float* __restrict__ g_cw, float* __restrict__ loss_out,
+                                                   const float* __restrict__ batch_norm) {
   __shared__ float sm[4];
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   float l_mse = 0.f, l_ent = 0.f, l_bce = 0.f;
@@ -25,8 +26,10 @@ __global__ __launch_bounds__(256) void k_loss_rays(const float* __restrict__ rgb
   // waiting for a separate single-block kernel
   float part = 0.f;
   for (int i = threadIdx.x; i < n_rays; i += 256) part += mask_px[i];
-  const float msum = block_sum256(part, sm);
-  if (blockIdx.x == 0 && threadIdx.x == 0) mask_sum[0] = msum;
+  const float msum_local = block_sum256(part, sm);
+  if (blockIdx.x == 0 && threadIdx.x == 0) mask_sum[0] = msum_local;
+  // ray-sharded data parallelism: the masked MSE is normalised by the UNION batch's masked-pixel count / world size
+  const float msum = batch_norm ? batch_norm[0] : msum_local;
   const float invN = 1.f / (float)n_rays;
   if (r < n_rays) {
     float y = mask_px[r];
@@ -60,11 +63,13 @@ __global__ __launch_bounds__(256) void k_loss_samples(const float* __restrict__ 
                                                       const int32_t* __restrict__ count, int capacity, float w_eik,
                                                       float w_dyn, float ls, float* __restrict__ g_gradient,
                                                       float* __restrict__ g_gdef, float* __restrict__ g_corr,
-                                                      float* __restrict__ g_sdef, float* __restrict__ loss_out) {
+                                                      float* __restrict__ g_sdef, float* __restrict__ loss_out,
+                                                      const float* __restrict__ batch_norm) {
   __shared__ float sm[4];
   int m = blockIdx.x * blockDim.x + threadIdx.x;
   int M = min(count[0], capacity);
   float invM = M > 0 ? 1.f / (float)M : 0.f;
+  if (batch_norm) invM = batch_norm[1] > 0.f ? 1.f / batch_norm[1] : 0.f;   // union batch's sample count / world size
   float l_eik = 0.f, l_gd = 0.f, l_c = 0.f, l_sd = 0.f;
   if (m < M) {
     float g[3] = {gradient[m * 3], gradient[m * 3 + 1], gradient[m * 3 + 2]};
@@ -102,7 +107,8 @@ __global__ __launch_bounds__(256) void k_loss_samples(const float* __restrict__ 
 extern "C" int pp_loss_rays(const float* rgb_marched, const float* alphainv_last, const float* cum_weights,
                             const float* target, const float* mask_px, float* mask_sum, int32_t n_rays, float w_main,
                             float w_entropy, float w_mask, float loss_scale, float* g_rgb_marched,
-                            float* g_alphainv_last, float* g_cum_weights, float* loss_out, void* stream) {
+                            float* g_alphainv_last, float* g_cum_weights, float* loss_out, const float* batch_norm,
+                            void* stream) {
   PP_REQUIRE(rgb_marched && alphainv_last && cum_weights && target && mask_px && mask_sum && g_rgb_marched &&
                  g_alphainv_last && g_cum_weights,
              "null pointer");
@@ -110,7 +116,7 @@ extern "C" int pp_loss_rays(const float* rgb_marched, const float* alphainv_last
   hipStream_t st = pp_stream(stream);
   hipLaunchKernelGGL(k_loss_rays, dim3(pp_div_up(n_rays, 256)), dim3(256), 0, st, rgb_marched, alphainv_last,
                      cum_weights, target, mask_px, mask_sum, n_rays, w_main, w_entropy, w_mask, loss_scale,
-                     g_rgb_marched, g_alphainv_last, g_cum_weights, loss_out);
+                     g_rgb_marched, g_alphainv_last, g_cum_weights, loss_out, batch_norm);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }
@@ -118,14 +124,15 @@ extern "C" int pp_loss_rays(const float* rgb_marched, const float* alphainv_last
 extern "C" int pp_loss_samples(const float* gradient, const float* grad_deform, const float* warp_out,
                                const float* sdf_deform, const int32_t* count, int32_t capacity, float w_eikonal,
                                float w_deform, float loss_scale, float* g_gradient, float* g_grad_deform,
-                               float* g_correction, float* g_sdf_deform, float* loss_out, void* stream) {
+                               float* g_correction, float* g_sdf_deform, float* loss_out, const float* batch_norm,
+                               void* stream) {
   PP_REQUIRE(gradient && grad_deform && warp_out && sdf_deform && count && g_gradient && g_grad_deform &&
                  g_correction && g_sdf_deform,
              "null pointer");
   PP_REQUIRE(capacity > 0, "capacity<=0");
   hipLaunchKernelGGL(k_loss_samples, dim3(pp_div_up(capacity, 256)), dim3(256), 0, pp_stream(stream), gradient,
                      grad_deform, warp_out, sdf_deform, count, capacity, w_eikonal, w_deform, loss_scale, g_gradient,
-                     g_grad_deform, g_correction, g_sdf_deform, loss_out);
+                     g_grad_deform, g_correction, g_sdf_deform, loss_out, batch_norm);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }

@@ -330,12 +330,8 @@ struct SideLane {
   }
 };
 
-// PP_MLP_FUSED=0 selects the layer-by-layer kernels (A/B measurements, generic shapes always use them)
-static bool mlp_fused_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PP_MLP_FUSED"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
+// option "mlp_fused" = 0 selects the layer-by-layer kernels (A/B measurements, generic shapes always use them)
+static bool mlp_fused_enabled() { return pp_opt(PP_OPT_MLP_FUSED) == 1; }
 
 static const int GEMM_MAX_WG = 256 * 5;     // 5 resident work-groups per CU at BM=64 (25 KB LDS, 90 regs)
 static const int GEMM_MAX_WG_SHARED = 256 * 3;   // when a weight-gradient GEMM runs beside it (register file: 2 x 96 + 2 x 144)
@@ -520,6 +516,61 @@ extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* a
   hipLaunchKernelGGL(k_warp_l0_bwd_w, dim3(pp_div_up(capacity, STRIP0)), b, 0, st, pts, cur, count, capacity,
                      params_grad + WP_W0, params_grad + WP_B0);
   side.join(0);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Two-stage forms of the layer-fused backward chains: the data-gradient kernel (which also produces the thin layers' and
+// all bias gradients and leaves Ybar of the hidden layers in `scratch`) and the weight-gradient kernel are separate entry
+// points, so that a caller can time them, place other work between them, or run the second on another stream.
+// pp_warp_bwd / pp_rgbnet_bwd are exactly stage 1 followed by stage 2.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int pp_warp_bwd_data(const float* params, const float* pts, const float* acts, const float* out_grad,
+                                const int32_t* count, int32_t capacity, float out_range, float* scratch,
+                                float* params_grad, float* pts_grad, void* stream) {
+  PP_REQUIRE(params && pts && acts && out_grad && count && scratch && params_grad && pts_grad, "null pointer");
+  PP_REQUIRE(capacity > 0, "capacity<=0");
+  if (!mlp_fused_enabled()) { pp_set_error("pp_warp_bwd_data: option mlp_fused = 0 has no two-stage form"); return PP_ERR_UNSUPPORTED; }
+  pp_launch_warp_fused_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad,
+                           pp_stream(stream));
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_warp_bwd_weights(const float* acts, const float* scratch, const int32_t* count, int32_t capacity,
+                                   float* params_grad, void* stream) {
+  PP_REQUIRE(acts && scratch && count && params_grad, "null pointer");
+  PP_REQUIRE(capacity > 0, "capacity<=0");
+  if (!mlp_fused_enabled()) { pp_set_error("pp_warp_bwd_weights: option mlp_fused = 0 has no two-stage form"); return PP_ERR_UNSUPPORTED; }
+  const int rcap = capacity * 4;
+  const size_t LS = (size_t)rcap * 128;
+  pp_launch_wgrad_chain(scratch, acts + 2 * LS, params_grad + WP_W3, scratch + LS, acts + LS, params_grad + WP_W2,
+                        scratch + 2 * LS, acts, params_grad + WP_W1, 128, count, 4, rcap, pp_stream(stream));
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_rgbnet_bwd_data(const float* params, const float* acts, const float* rgb, const float* rgb_grad,
+                                  const int32_t* count, int32_t capacity, float* scratch, float* params_grad,
+                                  float* feat_grad, void* stream) {
+  PP_REQUIRE(params && acts && rgb && rgb_grad && count && scratch && params_grad && feat_grad, "null pointer");
+  PP_REQUIRE(capacity > 0, "capacity<=0");
+  if (!mlp_fused_enabled()) { pp_set_error("pp_rgbnet_bwd_data: option mlp_fused = 0 has no two-stage form"); return PP_ERR_UNSUPPORTED; }
+  pp_launch_rgb_fused_bwd(params, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad, nullptr, 0,
+                          pp_stream(stream));
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_rgbnet_bwd_weights(const float* feat, const float* acts, const float* scratch, const int32_t* count,
+                                     int32_t capacity, float* params_grad, void* stream) {
+  PP_REQUIRE(feat && acts && scratch && count && params_grad, "null pointer");
+  PP_REQUIRE(capacity > 0, "capacity<=0");
+  if (!mlp_fused_enabled()) { pp_set_error("pp_rgbnet_bwd_weights: option mlp_fused = 0 has no two-stage form"); return PP_ERR_UNSUPPORTED; }
+  const size_t FLS = (size_t)capacity * 128;
+  pp_launch_wgrad_chain(scratch, acts + FLS, params_grad + RGF_W2, scratch + FLS, acts, params_grad + RGF_W1,
+                        scratch + 2 * FLS, feat, params_grad + RGF_W0, 64, count, 1, capacity, pp_stream(stream));
   PP_CHECK_LAUNCH();
   return PP_OK;
 }

@@ -729,15 +729,11 @@ __global__ __launch_bounds__(256) void k_wgrad_chain(WgradLayer LA, WgradLayer L
   wgrad_flush<KXC>(LC.Wbar, accC, wr, wc, l31, lh);
 }
 
-// PP_WGRAD_SPLIT=1 replaces the fp32-instruction chain kernel above by three launches of the self-scaling split-precision
+// option "wgrad_split" = 1 replaces the fp32-instruction chain kernel above by three launches of the self-scaling split-precision
 // kernel.  Parity suite green, but SLOWER on MI355X (1.405 vs 1.356 ms per step): the chain kernel reads each operand once,
 // keeps 192 accumulators resident and is hand-scheduled; three load-bound launches with an extra barrier per chunk are not
 // a match for it.  Off by default; kept as the starting point for a fused split-precision chain.
-static bool wgrad_split_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PP_WGRAD_SPLIT"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
+static bool wgrad_split_enabled() { return pp_opt(PP_OPT_WGRAD_SPLIT) == 1; }
 
 int pp_launch_wgrad_chain(const float* YA, const float* XA, float* WA, const float* YB, const float* XB, float* WB,
                           const float* YC, const float* XC, float* WC, int kxc, const int32_t* count, int rmul, int rcap,

@@ -1,7 +1,7 @@
 // Scene branch (lib/bg_nerf): the 8 x 256 NeRF MLP with BARF positional encoding and exp-cumsum compositing, forward and
 // backward.  fp32 in memory, fp32 accumulation, fp32-accurate matrix products: every product runs as three fp16 products on
-// v_mfma_f32_32x32x16_f16 (pp_gemm_split.h; error against fp64 equal to the fp32 matrix instructions'); PP_NERF_SPLIT=0
-// selects the fp32 instructions (pp_gemm.h) for all of them, PP_NERF_SPLIT_TN=0 for the weight gradients only.
+// v_mfma_f32_32x32x16_f16 (pp_gemm_split.h; error against fp64 equal to the fp32 matrix instructions'); option
+// "nerf_split" = 0 selects the fp32 instructions (pp_gemm.h) for all of them, "nerf_split_tn" = 0 for the weight gradients only.
 //
 //   reference: lib/bg_nerf/source/models/frequency_nerf.py
 //     :42-69    FrequencyEmbedder          (sin / cos of 2^l * pi * x, layout [coordinate][sin|cos][band])
@@ -21,7 +21,6 @@
 #include "pp_common.h"
 #include "pp_gemm.h"
 #include "pp_gemm_split.h"
-#include <stdlib.h>
 
 #define NERF_L3D 10
 #define NERF_LV 4
@@ -517,32 +516,30 @@ __global__ __launch_bounds__(256) void k_nerf_encode_bwd(const float* __restrict
 
 // ------------------------------------------------------------------------------------------------ host side
 static const int NERF_BM = 128;
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && atoi(e) > 0) ? atoi(e) : dflt; }
-static bool env_flag(const char* name, bool dflt) { const char* e = getenv(name); return (e && e[0]) ? (e[0] == '1') : dflt; }
-static const int NERF_GEMM_WGS = env_int("PP_NERF_GEMM_WGS", 256);     // persistent work-groups per column block (measured: 256 = 512 > 384 > 128)
+// Tuning options (pp_set_option; defaults = the measured best on MI355X):
+//   nerf_gemm_wgs      persistent work-groups per column block (256 = 512 > 384 > 128)
+//   nerf_tn_ch         rows per LDS chunk of the fp32 weight-gradient GEMM (32 | 64)
+//   nerf_tn_split_wgs  row splits of the split-precision weight-gradient kernel
+//   nerf_tn_wgs        row splits of a weight-gradient block: 128 x 4 blocks = 2 work-groups per CU, one round
+//   nerf_bn = 256      128 x 256 tiles for the fp32 NT GEMM (activation tile read once, half the barriers per MFMA).  Measured
+//                      SLOWER (3072 x 128 samples: 15.8 vs 13.8 ms per step): 128 accumulators + operand staging do not fit 256
+//                      registers without spills inside the K loop.  Kept for A/B runs.
+//   nerf_split         NT GEMMs (forward and data gradients) as three fp16 products with fp32 accumulation (pp_gemm_split.h:
+//                      error against fp64 equal to the fp32 matrix instructions', a third of their matrix-pipe time); 0 puts
+//                      them on the fp32 matrix instructions (A/B runs, bisecting)
+//   nerf_split_tn      the same for the weight-gradient products
+//   nerf_bitmask       one-bit ReLU masks (pp_gemm.h gemm_epilogue): the forward epilogue packs a lane's 16 rows of a column into
+//                      a 16-bit word, the data-gradient epilogue reads that word instead of 16 floats of the forward activation
+//                      (neutral for the exact-fp32 path, -11..-17 % with the split-precision path)
+#define NERF_GEMM_WGS pp_opt(PP_OPT_NERF_GEMM_WGS)
 static const int NERF_GEMM_WGS_WIDE = 512;   // 128 x 256 tiles: 2 resident per CU (55 KB LDS, ~220 registers)
-static const int NERF_TN_CH = env_int("PP_NERF_TN_CH", 64);           // rows per LDS chunk of the weight-gradient GEMM (32 | 64)
-static const int NERF_TN_SPLIT_WGS = env_int("PP_NERF_TN_SPLIT_WGS", 64);   // row splits of the split-precision weight-gradient kernel
-static const int NERF_TN_WGS = env_int("PP_NERF_TN_WGS", 128);        // row splits of a weight-gradient block: 128 x 4 blocks = 2 work-groups per CU, one round
-
-// PP_NERF_BN=256 selects 128 x 256 tiles (activation tile read once, half the barriers per MFMA).  Measured SLOWER on
-// MI355X (3072 x 128 samples: 15.8 vs 13.8 ms per step): 128 accumulators + operand staging do not fit 256 registers without
-// spills inside the K loop, and at 512 registers one work-group per CU cannot hide its own barriers.  Kept for A/B runs.
-static int nerf_wide_tiles() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PP_NERF_BN"); v = (e && atoi(e) == 256) ? 1 : 0; }
-  return v;
-}
-
-// The NT GEMMs (forward and data gradients) run as three fp16 products with fp32 accumulation (pp_gemm_split.h: error
-// against fp64 equal to the fp32 matrix instructions', a third of their matrix-pipe time); the weight-gradient GEMMs use the
-// fp32 matrix instructions.  PP_NERF_SPLIT=0 puts the NT GEMMs on the fp32 instructions as well (A/B runs, bisecting).
-static const bool NERF_SPLIT = env_flag("PP_NERF_SPLIT", true);
-static const bool NERF_SPLIT_TN = env_flag("PP_NERF_SPLIT_TN", true);    // weight-gradient products as three fp16 products too
-// One-bit ReLU masks (pp_gemm.h gemm_epilogue): the forward epilogue packs a lane's 16 rows of a column into a 16-bit word,
-// the data-gradient epilogue reads that word instead of 16 floats of the forward activation.  Neutral for the exact-fp32
-// path (12.1 vs 12.0 ms at 3072 x 128 samples), -11..-17 % with the split-precision path.  PP_NERF_BITMASK=0 switches them off.
-static const bool NERF_BITMASK = env_flag("PP_NERF_BITMASK", true);
+#define NERF_TN_CH pp_opt(PP_OPT_NERF_TN_CH)
+#define NERF_TN_SPLIT_WGS pp_opt(PP_OPT_NERF_TN_SPLIT_WGS)
+#define NERF_TN_WGS pp_opt(PP_OPT_NERF_TN_WGS)
+static int nerf_wide_tiles() { return pp_opt(PP_OPT_NERF_BN) == 256; }
+#define NERF_SPLIT (pp_opt(PP_OPT_NERF_SPLIT) == 1)
+#define NERF_SPLIT_TN (pp_opt(PP_OPT_NERF_SPLIT_TN) == 1)
+#define NERF_BITMASK (pp_opt(PP_OPT_NERF_BITMASK) == 1)
 
 template <int EPI>
 static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, int K, int Nout, const float* bias,

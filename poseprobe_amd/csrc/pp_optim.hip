@@ -178,7 +178,7 @@ extern "C" int pp_grid_tv_adam_step_sparse(const float* p_in, float* p_out, floa
   // chunks: a multiple of 8 when possible so that chunk <-> XCD (blocks are dealt round-robin over the 8 XCDs)
   // measured (tools/bench_grid.py, MI355X): 16 chunks win from 128 planes up (160^3: 272 -> 256 us dense), 8 below
   int n_chunks = nx >= 128 ? 16 : (nx >= 8 ? 8 : nx);
-  if (const char* ev = getenv("PP_GRID_CHUNKS")) { int c = atoi(ev); if (c > 0 && c <= nx) n_chunks = c; }   // tuning hook
+  { const int c = pp_opt(PP_OPT_GRID_CHUNKS); if (c > 0 && c <= nx) n_chunks = c; }   // tuning hook (option "grid_chunks")
   const int chunk_len = (nx + n_chunks - 1) / n_chunks;
   n_chunks = (nx + chunk_len - 1) / chunk_len;
   const int tiles = (int)((plane + 255) / 256);

@@ -235,7 +235,9 @@ __global__ __launch_bounds__(256) void k_sample_count(SceneDev sc, const float* 
   }
 }
 
-// exclusive scan of counts[0..n) into start[0..n], start[n] = total, count_out[0] = min(total, capacity)
+// exclusive scan of counts[0..n) into start[0..n], every entry clamped to the capacity: start[n] = count_out[0] =
+// min(total, capacity), so every per-ray range [start[r], start[r+1]) a later kernel walks lies inside the allocation (rays past
+// the capacity become empty, the ray that straddles it is cut)
 __global__ __launch_bounds__(1024) void k_exclusive_scan(const int32_t* __restrict__ counts, int n,
                                                          int32_t* __restrict__ start, int32_t* __restrict__ count_out,
                                                          int capacity) {
@@ -254,14 +256,15 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const int32_t* __restri
     int woff = 0;
     for (int w = 0; w < wid; ++w) woff += wsum[w];
     int carry = carry_s;
-    if (i < n) start[i] = carry + woff + x - v;
+    if (i < n) start[i] = min(carry + woff + x - v, capacity);
     __syncthreads();
     if (tid == 1023) carry_s = carry + woff + x;
     __syncthreads();
   }
   if (tid == 0) {
-    start[n] = carry_s;
-    count_out[0] = carry_s < capacity ? carry_s : capacity;
+    const int total = carry_s < capacity ? carry_s : capacity;
+    start[n] = total;
+    count_out[0] = total;
   }
 }
 

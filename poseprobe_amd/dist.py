@@ -8,9 +8,14 @@ link at W=2 and by a few links at W=8, so bytes on the wire are what matters).  
 mode "samples" (default) - exchange the k0 gradient at SAMPLE granularity
   * a rank's rays reach the dense 196 MB gradient grid through ~55 k samples only, so what travels is the INPUT of the
     scatter: 64 B per sample (12 feature gradients + position), one all-gather of [rows, 16] floats per rank instead of a
-    196 MB reduce-scatter plus a 196 MB all-gather; `rows` starts at the worst-case capacity (12 MB) and is cut to
-    1.5 x the largest sample count any rank has produced after two steps (5.4 MB at the bench workload; re-derived at
-    every resync); it overlaps the geometry / warp backward,
+    196 MB reduce-scatter plus a 196 MB all-gather.  `rows` is EXACT for every step: right after the sampler each rank
+    publishes (sample count, masked-pixel count) in a 8-byte all-gather that completes under the forward pass; the host
+    reads the counts from pinned memory when it enqueues the exchange (a wait on an event the GPU passed ~0.5 ms of queued
+    work earlier - the launch queue stays full) and sends the largest count rounded up to 1024 rows (3.6 MB per rank at
+    the bench workload instead of the 12 MB worst case).  No sample is ever dropped, no calibration window exists; the
+    exchange overlaps the geometry / warp backward,
+  * the same 8 bytes normalise the losses over the UNION batch (lib/losses.py divides the masked MSE by the batch's
+    masked-pixel count and the sample priors by the batch's sample count), so W ranks x N rays reproduce one W*N-ray step,
   * every rank replays the scatter for all shards (15 us each) and runs the full fused TV+Adam pass (replicated),
   * no parameter all-gather.  Float atomics make the replicas differ in the last bit, so every `resync_every` steps
     rank 0 broadcasts grid + moments (amortised to ~20 us / step).
@@ -37,7 +42,7 @@ def slab_bounds(X, world, rank):
 
 
 class DistContext:
-    def __init__(self, group=None, mode=None, resync_every=256, calib_steps=2, xcap_margin=1.5):
+    def __init__(self, group=None, mode=None, resync_every=256, row_quantum=1024):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -48,13 +53,11 @@ class DistContext:
         self.resync_every = resync_every
         self._gathered = None
         self._steps = 0
-        # mode "samples": rows of the packed buffer that travel.  The compacted sample list fills only part of its
-        # worst-case capacity (29 % at the bench workload), so after `calib_steps` steps the exchange is cut to
-        # `xcap_margin` x the largest count any rank has seen (one host read + one MAX all-reduce, again at every resync).
-        self.calib_steps, self.xcap_margin = calib_steps, xcap_margin
-        self.xcap = None                   # None: full capacity
-        self._max_count = None
-        self.overflows = 0                 # windows in which some rank produced more samples than were exchanged
+        # mode "samples": rows of the packed buffer that travel = the step's largest per-rank sample count, rounded up
+        self.row_quantum = row_quantum
+        self.rows = None                   # rows exchanged by the latest step (diagnostics / tests)
+        self.batch_norm = None             # device float[2]: union-batch normalisers of the losses (see start_batch_stats)
+        self._stats = None
 
     # ---- generic tensor-level collectives (also exercised on CPU with gloo) ---------------------------------
     def shardable(self, X):
@@ -147,15 +150,14 @@ class DistContext:
         if self.mode == 'samples':
             from . import ops
             ws = eng.ws
-            xcap = self.xcap or ws.cap
+            rows = self.rows = self.exchange_rows(self.step_counts().max(), ws.cap)
             if getattr(ws, 'k0_packed', None) is None:
                 ws.k0_packed = torch.zeros(ws.cap, 16, dtype=torch.float32, device=ws.pts.device)
-                self._max_count = torch.zeros(1, dtype=torch.int32, device=ws.pts.device)
-            if self._gathered is None or self._gathered.shape[1] != xcap:
-                self._gathered = torch.zeros(self.world, xcap, 16, dtype=torch.float32, device=ws.pts.device)
-            torch.maximum(self._max_count, ws.count, out=self._max_count)
-            ops.k0_pack_samples(ws.pts, ws.g_feat, ws.count, xcap, eng.cfg.k0_dim, ws.k0_packed)   # rows past xcap are dropped
-            _, self._grid_work = self.all_gather_rows(ws.k0_packed[:xcap], self._gathered, async_op=True)
+            if self._gathered is None or self._gathered.numel() != self.world * ws.cap * 16:
+                self._gathered = torch.zeros(self.world * ws.cap * 16, dtype=torch.float32, device=ws.pts.device)
+            ops.k0_pack_samples(ws.pts, ws.g_feat, ws.count, rows, eng.cfg.k0_dim, ws.k0_packed)
+            self._gathered_view = self._gathered[:self.world * rows * 16].view(self.world, rows, 16)
+            _, self._grid_work = self.all_gather_rows(ws.k0_packed[:rows], self._gathered_view, async_op=True)
             return
         X = eng.k0_grad.shape[0]
         if self.shardable(X) and self.backend != 'gloo':
@@ -171,7 +173,7 @@ class DistContext:
             from . import ops
             self._grid_work.wait()
             self._grid_work = None
-            ops.k0_scatter_packed(eng.cfg.pp, self._gathered, self.world, self._gathered.shape[1], eng.k0_grad,
+            ops.k0_scatter_packed(eng.cfg.pp, self._gathered_view, self.world, self._gathered_view.shape[1], eng.k0_grad,
                                   eng.k0_touched[eng.touch_par])
             eng.x_slab = (0, X)
             self.all_reduce_small([eng.flat.grad, eng.se3_grad], async_op=True)     # finished by wait_small() after the grid pass
@@ -204,8 +206,6 @@ class DistContext:
             resync = self.resync_every and self._steps % self.resync_every == 0
             if resync:
                 self.broadcast_state([eng.k0_cl, eng.k0_m, eng.k0_v])    # replicas differ in the last bit (float atomics)
-            if self._steps == self.calib_steps or resync:
-                self.calibrate_exchange(eng.ws.cap)
             return
         if self.shardable(X):
             if self.backend == 'gloo':
@@ -216,24 +216,59 @@ class DistContext:
                                                                async_op=True)
 
     def exchange_rows(self, max_count, cap):
-        """Rows to exchange for a largest observed count: margin, 1024-row granularity, never above the capacity."""
-        return int(min(cap, -(-int(max_count * self.xcap_margin + 1024) // 1024) * 1024))
+        """Rows to exchange for the step's largest per-rank count: rounded up to the row quantum, at least one quantum
+        (row 0 carries the count), never above the capacity (the sampler clamps counts to it)."""
+        q = self.row_quantum
+        return int(min(cap, max(q, -(-int(max_count) // q) * q)))
 
-    def calibrate_exchange(self, cap):
-        """(Re)size the sample exchange from the largest count any rank produced since the last call (the only host
-        synchronisation of the mode; every rank computes the same value).  A window whose count exceeded what travelled had
-        the tail of that rank's samples dropped on EVERY rank alike - replicas stay identical - and is counted in `overflows`."""
-        if self._max_count is None:
-            return
-        mx = self._max_count.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
-        m = int(mx.item())
-        if self.xcap is not None and m > self.xcap:
-            self.overflows += 1
-        self.xcap = max(self.exchange_rows(m, cap), 1024) if m > 0 else None
-        if self.xcap is not None and self.xcap >= cap:
-            self.xcap = None
-        self._max_count.zero_()
+    # ---- per-step batch statistics: sizes the sample exchange and normalises the losses over the union batch -----------
+    def start_batch_stats(self, count, mask_px):
+        """Called right after the sampler.  Publishes this rank's (masked-pixel count, sample count) to every rank
+        (all-gather of 2 floats, asynchronous: it completes under the forward pass), leaves `batch_norm` = column sums / W on
+        the device for the loss kernels (pp_loss_rays / pp_geometry_bwd_priors) and the per-rank counts in pinned host
+        memory for step_counts().  Counts are exact in fp32 (< 2^24 samples per rank)."""
+        dev = count.device
+        if self._stats is None or self._stats['local'].device != dev:
+            f = dict(dtype=torch.float32, device=dev)
+            st = self._stats = dict(local=torch.zeros(2, **f), all=torch.zeros(self.world, 2, **f), norm=torch.zeros(2, **f),
+                                    host=torch.zeros(self.world, 2, dtype=torch.float32))
+            if dev.type == 'cuda':
+                st['host'] = st['host'].pin_memory()
+                st['side'], st['ready'], st['landed'] = torch.cuda.Stream(dev), torch.cuda.Event(), torch.cuda.Event()
+        st = self._stats
+        torch.sum(mask_px.reshape(-1), dim=0, keepdim=True, out=st['local'][0:1])
+        st['local'][1:2].copy_(count)
+        _, work = self.all_gather_rows(st['local'], st['all'], async_op=(dev.type == 'cuda'))
+        if dev.type == 'cuda':
+            # everything downstream of the tiny collective runs on a side stream, so the compute stream never waits for it
+            # before it has to (the loss kernels, a whole forward pass later)
+            with torch.cuda.stream(st['side']):
+                work.wait()
+                torch.sum(st['all'], dim=0, out=st['norm'])
+                st['norm'].mul_(1.0 / self.world)
+                st['ready'].record()
+                st['host'].copy_(st['all'], non_blocking=True)
+                st['landed'].record()
+        else:
+            torch.sum(st['all'], dim=0, out=st['norm'])
+            st['norm'].mul_(1.0 / self.world)
+            st['host'].copy_(st['all'])
+        self.batch_norm = st['norm']
+
+    def wait_batch_stats(self):
+        """Compute stream waits (device side, no host involvement) until `batch_norm` is valid; -> batch_norm."""
+        st = self._stats
+        if st is not None and 'ready' in st:
+            torch.cuda.current_stream().wait_event(st['ready'])
+        return self.batch_norm
+
+    def step_counts(self):
+        """Per-rank sample counts of the current step (host tensor [W]).  The only host-side wait of the mode: on an event
+        recorded right after the sampler, i.e. the GPU is by then at most one forward pass behind the host."""
+        st = self._stats
+        if 'landed' in st:
+            st['landed'].synchronize()
+        return st['host'][:, 1]
 
     def wait_parameters(self, eng):
         work = getattr(self, '_param_work', None)

@@ -247,10 +247,10 @@ class RenderCore:
             after_k0_grad()             # multi-GPU: the grid reduce-scatter overlaps the rest of the backward
         if priors is not None:
             # fused step: the sample-level priors (eikonal, deformation) are differentiated inside the geometry backward
-            w_eik, w_dyn, ls, loss_out = priors
+            w_eik, w_dyn, ls, loss_out, batch_norm = priors
             ops.geometry_bwd_priors(sc, sdf, sdf_ab, ws.pts, ws.warp_out, ws.viewdirs, ws.ray_id, ws.count, ws.cap, inv_s,
                                     ws.g_alpha, ws.g_gradient, w_eik, w_dyn, ls, 1, ws.g_warp_out, ws.g_pts, ws.g_view_s,
-                                    sdf_ab_grad, loss_out)
+                                    sdf_ab_grad, loss_out, batch_norm)
         else:
             if g_gradient_ext is not None:
                 g_gradient_ext(ws)      # callable adding loss terms into ws.g_gradient etc.
@@ -371,6 +371,10 @@ class TrainEngine:
         ops.raygen_select_fwd(sc, ray_idx, self.c2w, self.intr, self.H, self.W, cfg.inverse_y, True, self.images, self.masks,
                               ws.rays_o, ws.rays_d, ws.viewdirs, ws.target, ws.mask_px)
         self.core.sample(ws, jitter)
+        if self.dist is not None:
+            # (sample count, masked-pixel count) of every rank: sizes the sample exchange exactly and normalises the losses
+            # over the union batch; the 8-byte all-gather completes under the forward pass
+            self.dist.start_batch_stats(ws.count, ws.mask_px)
         progress = global_step / cfg.N_iters
         self._upload_step_scalars(progress)
         s_val = cfg.s_val(global_step)
@@ -381,8 +385,9 @@ class TrainEngine:
         ws.zero_block.zero_()
         w_dyn = dynamic_weight(1e-1, 1e-3, global_step, cfg.N_iters)
         ls = self.loss_scale
+        batch_norm = None if self.dist is None else self.dist.wait_batch_stats()
         ops.loss_rays(ws.rgb_marched, ws.alphainv_last, ws.cum_weights, ws.target, ws.mask_px, ws.mask_sum, self.w_main,
-                      0.01, self.w_mask, ls, ws.g_rgbm, ws.g_last, ws.g_cw, ws.loss_out)
+                      0.01, self.w_mask, ls, ws.g_rgbm, ws.g_last, ws.g_cw, ws.loss_out, batch_norm)
 
         # The k0 scatter is issued from here (not inside colour-feature backward) so that it can mark the voxels it reaches:
         # single GPU = right after the colour-feature backward; multi-GPU "samples" mode = replayed for all ranks' gathered
@@ -399,7 +404,7 @@ class TrainEngine:
                 self.dist.start_grid_reduce(self)
         self.core.backward(ws, self.k0_cl, self.sdf, P.view('sdf_ab'), P.view('rgbnet'), P.view('warp'), inv_s, self.pe_w,
                            k0_grad, P.view('sdf_ab', 'grad'), P.view('rgbnet', 'grad'), P.view('warp', 'grad'),
-                           priors=(1.0, w_dyn, ls, ws.loss_out),
+                           priors=(1.0, w_dyn, ls, ws.loss_out, batch_norm),
                            after_k0_grad=after_k0, defer_join=True)
         ctx = ops.side_context() if self.core.use_side_stream else None
         ops.raygen_select_bwd(sc, ray_idx, self.c2w, self.intr, self.H, self.W, cfg.inverse_y, ws.rays_o, ws.rays_d,

@@ -160,11 +160,12 @@ def color_feat_bwd(sc, k0_cl, pts, viewdirs, ray_id, gradient, pe_w, count, capa
 
 
 def geometry_bwd_priors(sc, sdf_grid, sdf_ab, pts, warp_out, viewdirs, ray_id, count, capacity, inv_s, g_alpha, g_gradient,
-                        w_eikonal, w_deform, loss_scale, accumulate, warp_out_grad, pts_grad, vgrad_s, sdf_ab_grad, loss_out):
+                        w_eikonal, w_deform, loss_scale, accumulate, warp_out_grad, pts_grad, vgrad_s, sdf_ab_grad, loss_out,
+                        batch_norm=None):
     _lib.call('pp_geometry_bwd_priors', ctypes.byref(sc), _f(sdf_grid), _f(sdf_ab), _f(pts), _f(warp_out), _f(viewdirs),
               _i(ray_id), _i(count), capacity, float(inv_s), _f(g_alpha), _f(g_gradient), float(w_eikonal), float(w_deform),
               float(loss_scale), int(accumulate), _f(warp_out_grad), _f(pts_grad), _f(vgrad_s), _f(sdf_ab_grad),
-              _f(loss_out), _stream())
+              _f(loss_out), _f(batch_norm), _stream())
 
 
 def k0_pack_samples(pts, feat_grad, count, capacity, k0_dim, packed):
@@ -219,19 +220,37 @@ def warp_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, p
               _f(scratch), _f(params_grad), _f(pts_grad), ctx, _stream())
 
 
+def warp_bwd_data(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad):
+    _lib.call('pp_warp_bwd_data', _f(params), _f(pts), _f(acts), _f(out_grad), _i(count), capacity, float(out_range),
+              _f(scratch), _f(params_grad), _f(pts_grad), _stream())
+
+
+def warp_bwd_weights(acts, scratch, count, capacity, params_grad):
+    _lib.call('pp_warp_bwd_weights', _f(acts), _f(scratch), _i(count), capacity, _f(params_grad), _stream())
+
+
+def rgbnet_bwd_data(params, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad):
+    _lib.call('pp_rgbnet_bwd_data', _f(params), _f(acts), _f(rgb), _f(rgb_grad), _i(count), capacity, _f(scratch),
+              _f(params_grad), _f(feat_grad), _stream())
+
+
+def rgbnet_bwd_weights(feat, acts, scratch, count, capacity, params_grad):
+    _lib.call('pp_rgbnet_bwd_weights', _f(feat), _f(acts), _f(scratch), _i(count), capacity, _f(params_grad), _stream())
+
+
 # ------------------------------------------------------------------------------------------- losses / optimiser
 def loss_rays(rgb_marched, alphainv_last, cum_weights, target, mask_px, mask_sum, w_main, w_entropy, w_mask,
-              loss_scale, g_rgbm, g_last, g_cw, loss_out):
+              loss_scale, g_rgbm, g_last, g_cw, loss_out, batch_norm=None):
     _lib.call('pp_loss_rays', _f(rgb_marched), _f(alphainv_last), _f(cum_weights), _f(target), _f(mask_px),
               _f(mask_sum), rgb_marched.shape[0], float(w_main), float(w_entropy), float(w_mask), float(loss_scale),
-              _f(g_rgbm), _f(g_last), _f(g_cw), _f(loss_out), _stream())
+              _f(g_rgbm), _f(g_last), _f(g_cw), _f(loss_out), _f(batch_norm), _stream())
 
 
 def loss_samples(gradient, grad_deform, warp_out, sdf_deform, count, capacity, w_eik, w_deform, loss_scale, g_gradient,
-                 g_grad_deform, g_correction, g_sdf_deform, loss_out):
+                 g_grad_deform, g_correction, g_sdf_deform, loss_out, batch_norm=None):
     _lib.call('pp_loss_samples', _f(gradient), _f(grad_deform), _f(warp_out), _f(sdf_deform), _i(count), capacity,
               float(w_eik), float(w_deform), float(loss_scale), _f(g_gradient), _f(g_grad_deform), _f(g_correction),
-              _f(g_sdf_deform), _f(loss_out), _stream())
+              _f(g_sdf_deform), _f(loss_out), _f(batch_norm), _stream())
 
 
 def grid_tv_adam_step(p_in, p_out, grad, exp_avg, exp_avg_sq, size, channels, x_begin, x_end, tv_scale, grad_scale, lr,

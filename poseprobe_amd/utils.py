@@ -79,53 +79,99 @@ class Adam(torch.optim.Optimizer):
         return loss
 
 
+def _optimised_attributes(model, cfg_train):
+    """(name, attribute, base lr) for every `lrate_<name>` entry of the training config that names an existing,
+    non-None attribute of the model - the coupling the reference's optimiser builder relies on."""
+    rows = []
+    for key in cfg_train.keys():
+        name = key[6:] if key.startswith('lrate_') else None
+        attr = getattr(model, name, None) if name else None
+        if attr is not None:
+            rows.append((name, attr, getattr(cfg_train, key)))
+    return rows
+
+
 def create_optimizer_or_freeze_model(model, cfg_train, global_step):
-    """lib/utils.py:316-342: one param group per `lrate_<attr>` key, lr decayed to `global_step`, betas (0.9, 0.99)."""
-    decay_steps = cfg_train.lrate_decay * 1000
-    decay_factor = 0.1 ** (global_step / decay_steps)
-    param_group = []
-    for k in cfg_train.keys():
-        if not k.startswith('lrate_'):
-            continue
-        k = k[len('lrate_'):]
-        if not hasattr(model, k):
-            continue
-        param = getattr(model, k)
-        if param is None:
-            continue
-        lr = getattr(cfg_train, f'lrate_{k}') * decay_factor
-        if lr > 0:
-            if isinstance(param, nn.Module):
-                param = param.parameters()
-            param_group.append({'params': param, 'lr': lr, 'name': k})
+    """Counterpart of lib/utils.py:316-342.  One Adam group (betas 0.9 / 0.99) per trainable attribute, its learning rate
+    already decayed to `global_step` (factor 0.1 per `lrate_decay` thousand steps); attributes whose rate is not positive
+    are frozen instead of grouped."""
+    decayed = 0.1 ** (global_step / (cfg_train.lrate_decay * 1000))
+    groups = []
+    for name, attr, base_lr in _optimised_attributes(model, cfg_train):
+        tensors = list(attr.parameters()) if isinstance(attr, nn.Module) else [attr]
+        if base_lr * decayed > 0:
+            groups.append(dict(params=tensors, lr=base_lr * decayed, name=name))
         else:
-            if isinstance(param, nn.Module):
-                for q in param.parameters():
-                    q.requires_grad = False
-            else:
-                param.requires_grad = False
-    return Adam(param_group, betas=(0.9, 0.99))
+            for t in tensors:
+                t.requires_grad = False
+    return Adam(groups, betas=(0.9, 0.99))
 
 
 def create_optimizer_pose(model, cfg_train, max_iter=1, align=False, index=None):
-    """lib/utils.py:347-362"""
-    if align is False:
-        optim_pose = Adam([dict(params=model.se3_refine, lr=cfg_train.lr_pose)])
-    else:
-        optim_pose = Adam([dict(params=model.se3_align_refine, lr=1e-5)])
-    if cfg_train.sched_pose is None:
-        return optim_pose, None
-    assert cfg_train.sched_pose == 'ExponentialLR'
-    gamma = (cfg_train.lr_pose_end / (1e-10 + cfg_train.lr_pose)) ** (1. / max_iter)
-    return optim_pose, torch.optim.lr_scheduler.ExponentialLR(optim_pose, gamma=gamma)
+    """Counterpart of lib/utils.py:347-362: Adam on the 6-DoF refinement (or, with align=True, on the alignment refinement
+    at 1e-5) and, when the config asks for it, an exponential schedule that reaches `lr_pose_end` after `max_iter` steps."""
+    target, lr = (model.se3_align_refine, 1e-5) if align else (model.se3_refine, cfg_train.lr_pose)
+    optim = Adam([dict(params=target, lr=lr)])
+    kind = cfg_train.sched_pose
+    if kind is None:
+        return optim, None
+    if kind != 'ExponentialLR':
+        raise ValueError(f'sched_pose={kind!r}: only ExponentialLR is used by the reference configurations')
+    ratio = cfg_train.lr_pose_end / (1e-10 + cfg_train.lr_pose)
+    return optim, torch.optim.lr_scheduler.ExponentialLR(optim, gamma=ratio ** (1. / max_iter))
+
+
+def plain_kwargs(kwargs):
+    """Constructor kwargs with numpy arrays / scalars and tensors turned into plain Python lists and numbers, so that a
+    checkpoint holding them loads with `weights_only=True` and nothing else."""
+    def conv(v):
+        if isinstance(v, (np.ndarray, np.generic)):
+            return v.tolist()
+        if isinstance(v, torch.Tensor):
+            return v.detach().cpu().tolist()
+        if isinstance(v, dict):
+            return {k: conv(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [conv(x) for x in v]
+        return v
+    return {k: conv(v) for k, v in kwargs.items()}
+
+
+def _numpy_array_globals():
+    """The reconstructors a pickled numpy array needs - and nothing else: a reference checkpoint keeps `xyz_min`, `HW`,
+    `i_train`, ... as numpy arrays inside `model_kwargs` (lib/voxurf_coarse.py get_kwargs)."""
+    try:
+        from numpy._core import multiarray as ma
+    except ImportError:                                    # numpy < 2
+        from numpy.core import multiarray as ma
+    allowed = [np.ndarray, np.dtype, ma._reconstruct, ma.scalar]
+    allowed += [type(np.dtype(t)) for t in (np.float32, np.float64, np.int32, np.int64, np.uint8, np.bool_)]
+    return allowed
+
+
+def load_checkpoint_file(path):
+    """torch.load with weights_only=True; numpy arrays are the one extra thing admitted.  Nothing in the file is executed:
+    a checkpoint that needs any other global fails with torch's UnpicklingError instead of being unpickled."""
+    with torch.serialization.safe_globals(_numpy_array_globals()):
+        return torch.load(path, map_location='cpu', weights_only=True)
+
+
+def save_model(model, path, global_step=0, optimizer=None, **extra):
+    """Checkpoint in the reference's key layout (lib/recon_scene.py:779-791) with plain-list constructor kwargs."""
+    ck = {'global_step': int(global_step), 'model_kwargs': plain_kwargs(model.get_kwargs()),
+          'MaskCache_kwargs': plain_kwargs(model.get_MaskCache_kwargs()), 'model_state_dict': model.state_dict()}
+    if optimizer is not None:
+        ck['optimizer_state_dict'] = optimizer.state_dict()
+    ck.update(extra)
+    torch.save(ck, path)
 
 
 def load_model(model_class, ckpt_path, strict=True, device='cuda'):
-    """lib/utils.py:416-438: rebuild from `model_kwargs` and load `model_state_dict` (files written by this package;
-    reference checkpoints contain pickled numpy arrays in `model_kwargs` and need weights_only=False on the user's side)."""
-    ckpt = torch.load(ckpt_path, map_location='cpu', weights_only=False)
+    """Counterpart of lib/utils.py:416-438: rebuild the model from `model_kwargs`, load `model_state_dict`.  Reads files
+    written by this package (save_model, TrainEngine.save_checkpoint) and reference checkpoints alike, always weights-only."""
+    ckpt = load_checkpoint_file(ckpt_path)
     model = model_class(**ckpt['model_kwargs'])
-    sd = ckpt['model_state_dict']
+    sd = dict(ckpt['model_state_dict'])
     sd.pop('s_val', None)        # only present when the reference model was built on CPU (voxurf_coarse.py:94)
     model.load_state_dict(sd, strict=strict)
     return model.to(device)

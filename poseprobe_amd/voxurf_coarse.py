@@ -675,15 +675,10 @@ def get_rays_of_a_view(H, W, K, c2w, ndc, inverse_y, flip_x, flip_y, mode='cente
 
 
 def ndc_rays(H, W, focal, near, rays_o, rays_d):
-    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
-    rays_o = rays_o + t[..., None] * rays_d
-    o0 = -1. / (W / (2. * focal)) * rays_o[..., 0] / rays_o[..., 2]
-    o1 = -1. / (H / (2. * focal)) * rays_o[..., 1] / rays_o[..., 2]
-    o2 = 1. + 2. * near / rays_o[..., 2]
-    d0 = -1. / (W / (2. * focal)) * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
-    d1 = -1. / (H / (2. * focal)) * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
-    d2 = -2. * near / rays_o[..., 2]
-    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+    """lib/voxurf_coarse.py:1371-1399.  No PoseProbe configuration sets ndc=True (forward-facing LLFF scenes only) and the
+    HIP sampler has no NDC parametrisation, so the name exists for API parity and refuses instead of rendering wrongly."""
+    raise NotImplementedError('ndc_rays (lib/voxurf_coarse.py:1371-1399): NDC rays are not used by any PoseProbe '
+                              'configuration and are not part of the HIP path')
 
 
 def select_training_rays(ray_idx, rgb_tr_ori, mask_tr_ori, train_poses, HW, Ks, inverse_y=True):

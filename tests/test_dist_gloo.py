@@ -136,17 +136,21 @@ def _worker_samples(rank, world, port, q):
     tot = sum(range(1, world + 1))
     ok = ok and bool((a == tot).all()) and bool((b == 10.0 * tot).all())
     ctx.wait_small()                                             # idempotent
-    # adaptive exchange size: every rank derives the same row count from the largest sample count any rank has seen
-    ctx._max_count = torch.tensor([3000 + 900 * rank], dtype=torch.int32)
-    ctx.calibrate_exchange(cap=16384)
-    ok = ok and ctx.xcap == ctx.exchange_rows(3000 + 900 * (world - 1), 16384) == 7168 and ctx.overflows == 0
-    ok = ok and int(ctx._max_count) == 0
-    ctx._max_count = torch.tensor([9000 if rank == world - 1 else 100], dtype=torch.int32)      # one rank outgrew the exchange
-    ctx.calibrate_exchange(cap=16384)
-    ok = ok and ctx.overflows == 1 and ctx.xcap == 15360
-    ctx._max_count = torch.tensor([16000], dtype=torch.int32)
-    ctx.calibrate_exchange(cap=16384)
-    ok = ok and ctx.xcap is None                                 # back to the full capacity
+    # exact exchange size per step: every rank learns every rank's sample count right after its sampler and derives the same
+    # row count from the largest one - also when a rank suddenly produces far more samples than in any earlier step
+    for step, count_of in enumerate((lambda r: 3000 + 900 * r, lambda r: 15000 if r == world - 1 else 100, lambda r: 16384)):
+        mask = torch.zeros(64)
+        mask[:10 + 5 * rank + step] = 1.0
+        ctx.start_batch_stats(torch.tensor([count_of(rank)], dtype=torch.int32), mask)
+        counts = ctx.step_counts()
+        ok = ok and [int(c) for c in counts] == [count_of(r) for r in range(world)]
+        rows = ctx.exchange_rows(counts.max(), cap=16384)
+        ok = ok and rows % 1024 == 0 and rows >= max(count_of(r) for r in range(world)) and rows <= 16384
+        ok = ok and rows - max(count_of(r) for r in range(world)) < 1024
+        bn = ctx.wait_batch_stats()
+        ok = ok and abs(float(bn[1]) - sum(count_of(r) for r in range(world)) / world) < 1e-3
+        ok = ok and abs(float(bn[0]) - sum(10 + 5 * r + step for r in range(world)) / world) < 1e-6
+    ok = ok and ctx.exchange_rows(0, cap=16384) == 1024 and ctx.exchange_rows(5, cap=512) == 512
     if rank == 0:
         q.put(bool(ok))
     dist.destroy_process_group()
@@ -215,3 +219,104 @@ def test_scene_gradient_all_reduce_keeps_replicas_identical():
     ref_p.grad = torch.tensor(res[0][2])
     ref.step()
     assert torch.allclose(torch.tensor(res[0][1]), ref_p.detach(), rtol=0, atol=1e-7)
+
+
+def _union_loss(out, target, mask, gs, n_iters, norm_mask, norm_samples, n_rays):
+    """object_losses (oracle/voxurf_oracle.py:614-639 = lib/losses.py:34-74, tv weight 0) with explicit normalisers for the
+    masked MSE (masked-pixel count) and the sample-level priors (sample count): the quantities pp_loss_rays /
+    pp_geometry_bwd_priors take from `batch_norm` in the ray-sharded step."""
+    from oracle import voxurf_oracle as O
+    mse = (((out['rgb_marched'] - target) * mask) ** 2).sum() / (norm_mask * 3)
+    pout = out['alphainv_cum'].clamp(1e-6, 1 - 1e-6)
+    ent = -(pout * torch.log(pout) + (1 - pout) * torch.log(1 - pout)).sum() / n_rays
+    eik = torch.abs(out['gradient'].norm(dim=-1) - 1).sum() / norm_samples
+    w = O.dynamic_weight(1e-1, 1e-3, gs, n_iters)
+    gd = out['grad_deform'].norm(dim=-1).sum() / (3 * norm_samples)
+    sc = torch.abs(out['sdf_correct']).sum() / norm_samples
+    sd = torch.abs(out['sdf_deform']).sum() / norm_samples
+    bce = torch.nn.functional.binary_cross_entropy(out['cum_weights'].clip(1e-3, 1.0 - 1e-3), mask, reduction='sum') / n_rays
+    return mse + 0.01 * ent + eik + w * (gd + sc + sd) + 0.1 * bce
+
+
+def _worker_union(rank, world, port, q):
+    """W ranks x N rays with DistContext's batch statistics == one process with the union batch of W*N rays: the gradients of
+    the shared parameters (pose, alpha / beta, both MLPs) averaged over the ranks equal the union step's."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from oracle import voxurf_oracle as O
+    from poseprobe_amd import synthetic as syn
+    from poseprobe_amd.dist import DistContext
+    from tests.helpers import scene_for
+    ctx = DistContext(mode='samples')
+    G, V, H, W, N, gs = 12, 3, 16, 16, 48, 10
+    scene = scene_for(G)
+    views = syn.make_views(V, H, W)
+    idx, jit = syn.step_randomness(V * H * W, N * world, seed=5)
+
+    def grads_of(sel, norm=None):
+        P = O.params_require_grad(O.init_params(scene, seed=2))
+        se3 = torch.tensor(syn.se3_perturbation(V), requires_grad=True)
+        c2w = O.pose_invert(O.current_pose_pnp(se3, torch.tensor(views['w2c'])))
+        ro, rd, vd, target, mask = O.select_training_rays(torch.tensor(idx[sel]), torch.tensor(views['images']),
+                                                          torch.tensor(views['masks']), torch.tensor(views['Ks']), c2w)
+        out = O.voxurf_forward(P, scene, ro, rd, vd, jitter=torch.tensor(jit[sel]), global_step=gs)
+        M = out['weights'].shape[0]
+        if norm is None:
+            nm, ns = mask.sum(), float(M)
+        else:
+            bn = norm(torch.tensor([M], dtype=torch.int32), mask)
+            nm, ns = bn[0], bn[1]
+        _union_loss(out, target, mask, gs, scene.N_iters, nm, ns, len(ro)).backward()
+        flat = [se3.grad.reshape(-1), P['sdf_alpha'].grad, P['sdf_beta'].grad]
+        flat += [t.grad.reshape(-1) for Wb in P['rgbnet'] + P['warp'] for t in Wb]
+        return torch.cat(flat), M
+
+    def norm(count, mask):
+        ctx.start_batch_stats(count, mask)
+        return ctx.wait_batch_stats()
+
+    g_mine, M_mine = grads_of(slice(rank, None, world), norm)
+    ctx.all_reduce_tensor(g_mine)
+    g_mine /= world
+    if rank == 0:
+        g_union, M_union = grads_of(slice(None))
+        # and the oracle's own object_losses on the union batch is the same function
+        err = float((g_mine - g_union).abs().max() / g_union.abs().max())
+        q.put((err, int(ctx.step_counts().sum()), M_union))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_losses_equal_the_union_batch():
+    world, port = 2, _free_port()
+    ctxm = mp.get_context('spawn')
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_worker_union, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    err, m_sum, m_union = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert m_sum == m_union
+    assert err < 2e-5, err
+
+
+def test_union_loss_helper_is_the_oracle_loss():
+    """_union_loss with the batch's own counts == oracle object_losses (which is pinned to lib/losses.py by the fixtures)."""
+    from oracle import voxurf_oracle as O
+    from poseprobe_amd import synthetic as syn
+    from tests.helpers import scene_for
+    scene = scene_for(12)
+    views = syn.make_views(3, 16, 16)
+    idx, jit = syn.step_randomness(3 * 16 * 16, 64, seed=5)
+    P = O.params_require_grad(O.init_params(scene, seed=2))
+    se3 = torch.tensor(syn.se3_perturbation(3), requires_grad=True)
+    c2w = O.pose_invert(O.current_pose_pnp(se3, torch.tensor(views['w2c'])))
+    ro, rd, vd, target, mask = O.select_training_rays(torch.tensor(idx), torch.tensor(views['images']),
+                                                      torch.tensor(views['masks']), torch.tensor(views['Ks']), c2w)
+    out = O.voxurf_forward(P, scene, ro, rd, vd, jitter=torch.tensor(jit), global_step=10)
+    ref = O.object_losses(out, target, mask, 10, scene.N_iters, weight_tv_k0=0.0)[2]
+    mine = _union_loss(out, target, mask, 10, scene.N_iters, mask.sum(), float(out['weights'].shape[0]), len(ro))
+    assert abs(float(ref) - float(mine)) < 1e-6 * abs(float(ref))

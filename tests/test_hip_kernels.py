@@ -96,6 +96,58 @@ def test_dense_sampler_indices_bit_exact(tag):
         assert int(ray_start[-1].item()) == M
 
 
+def test_dense_sampler_with_capacity_below_the_total_stays_inside_the_allocation():
+    """capacity < number of in-bbox samples: count and every ray_start entry are clamped, nothing past `capacity` rows is
+    written (guard rows keep their sentinel), rays in front of the cut are unchanged, and the per-ray kernels that walk
+    [ray_start[r], ray_start[r+1]) (transmittance scan forward / backward) stay inside the allocation."""
+    from poseprobe_amd import ops
+    d = load('sampler_g24.npz')
+    cfg = _cfg(d['G'])
+    ro, rd, jit = cu(d['rays_o']), cu(d['rays_d']), cu(d['jitter'])
+    N, S = ro.shape[0], cfg.n_samples
+    f, i = dict(device='cuda'), dict(device='cuda', dtype=torch.int32)
+
+    def run(cap, rows):
+        t_min, t_max = torch.empty(N, **f), torch.empty(N, **f)
+        ray_start, count = torch.empty(N + 1, **i), torch.empty(1, **i)
+        pts, step = torch.full((rows, 3), -777., **f), torch.full((rows,), -777., **f)
+        ray_id, step_k = torch.full((rows,), -7, **i), torch.full((rows,), -7, **i)
+        ops.sample_dense(cfg.pp, ro, rd, jit, cap, t_min, t_max, ray_start, count, pts, ray_id, step_k, step)
+        return ray_start.cpu().numpy(), int(count.item()), pts.cpu().numpy(), ray_id.cpu().numpy(), step_k.cpu().numpy(), step.cpu().numpy()
+
+    rs_full, M, pts_f, rid_f, sk_f, st_f = run(N * S, N * S)
+    cap = max(N, M * 2 // 3)
+    assert N <= cap < M
+    rs, cnt, pts, rid, sk, st = run(cap, cap + 4096)
+    assert cnt == cap and rs[-1] == cap
+    assert np.array_equal(rs, np.minimum(rs_full, cap))
+    assert (pts[cap:] == -777.).all() and (rid[cap:] == -7).all() and (sk[cap:] == -7).all() and (st[cap:] == -777.).all()
+    assert np.array_equal(pts[:cap], pts_f[:cap]) and np.array_equal(rid[:cap], rid_f[:cap])
+    assert np.array_equal(sk[:cap], sk_f[:cap]) and np.array_equal(st[:cap], st_f[:cap])
+    # consumers of ray_start: buffers have exactly `cap` rows + guard rows that must keep their sentinel
+    g = torch.Generator().manual_seed(0)
+    alpha = torch.full((cap + 4096,), -777., **f)
+    alpha[:cap] = (torch.rand(cap, generator=g) * 0.3).cuda()
+    w, T = torch.full((cap + 4096,), -777., **f), torch.full((cap + 4096,), -777., **f)
+    last, i_end = torch.empty(N, **f), torch.empty(N, **i)
+    rs_d = torch.tensor(rs, **i)
+    ops.alpha2weight_fwd(alpha, rs_d, N, w, T, last, i_end)
+    gw, gl, ga = torch.ones(cap + 4096, **f), torch.zeros(N, **f), torch.full((cap + 4096,), -777., **f)
+    ops.alpha2weight_bwd(alpha, w, T, last, rs_d, i_end, N, gw, gl, ga)
+    torch.cuda.synchronize()
+    assert float(w[cap:].max()) == -777. and float(T[cap:].max()) == -777. and float(ga[cap:].max()) == -777.
+    assert bool((i_end <= cap).all())
+    full_ray = np.nonzero(rs_full[1:] <= cap)[0]                 # rays in front of the cut: same result as an untruncated run
+    w2, T2 = torch.zeros(M, **f), torch.zeros(M, **f)
+    alpha2 = torch.zeros(M, **f)
+    alpha2[:cap] = alpha[:cap]
+    last2, i_end2 = torch.empty(N, **f), torch.empty(N, **i)
+    ops.alpha2weight_fwd(alpha2, torch.tensor(rs_full, **i), N, w2, T2, last2, i_end2)
+    assert torch.equal(last[full_ray], last2[full_ray])
+    e = int(rs_full[full_ray[-1] + 1])
+    assert torch.equal(w[:e], w2[:e])
+
+
 def _random_segments(n_rays, max_len, seed, hot=False):
     rng = np.random.RandomState(seed)
     lens = rng.randint(0, max_len, size=n_rays)

@@ -202,14 +202,49 @@ def test_scene_full_size_properties():
         assert_close(b, (-2.0 * a).cpu(), rtol=1e-3, scaled=1e-4, name='backward linearity')   # atomics: summation order differs
 
 
-def test_scene_backward_after_overwritten_forward_fails_loudly():
+def test_scene_pending_forward_passes_of_one_shape_keep_their_activations():
+    """Any number of forward passes of the same (R, S) may be pending before backward, as with the reference's autograd
+    (each differentiable pass owns its activation block); no_grad passes in between do not disturb them."""
     net, opt = _net()
-    c, r = torch.zeros(1, 8, 3).cuda().requires_grad_(True), torch.ones(1, 8, 3).cuda()
+    g = torch.Generator().manual_seed(3)
+    c1, c2 = (torch.randn(1, 8, 3, generator=g) * 0.2).cuda(), (torch.randn(1, 8, 3, generator=g) * 0.2).cuda()
+    r = torch.randn(1, 8, 3, generator=g).cuda()
     d = torch.linspace(0.5, 2, 4).cuda().reshape(1, 1, 4, 1).repeat(1, 8, 1, 1)
-    a = net.forward_samples(opt, c, r, d)
-    net.forward_samples(opt, c, r, d)
-    with pytest.raises(RuntimeError, match='overwritten'):
-        a['rgb_samples'].sum().backward()
+    params = [p for n, p in net.named_parameters() if n != 'progress']
+    singles = []
+    for c in (c1, c2):
+        net.zero_grad()
+        net.forward_samples(opt, c, r, d)['rgb_samples'].sum().backward()
+        singles.append([p.grad.clone() for p in params])
+    net.zero_grad()
+    a = net.forward_samples(opt, c1, r, d)
+    b = net.forward_samples(opt, c2, r, d)                       # same shape, pending together
+    with torch.no_grad():
+        net.forward_samples(opt, c2 * 3.0, r, d)                 # shares the per-shape scratch block, owns nothing
+    (a['rgb_samples'].sum() + b['rgb_samples'].sum()).backward()
+    for p, g1, g2 in zip(params, *singles):
+        assert_close(p.grad, (g1 + g2).cpu(), rtol=1e-4, scaled=1e-5, name='sum of two pending passes')
+
+
+def test_scene_engine_pass_between_autograd_forward_and_backward():
+    """SceneEngine's own forward / backward pair at the same (R, S) between an autograd forward and its backward."""
+    from poseprobe_amd import bg_nerf
+    net, opt = _net()
+    g = torch.Generator().manual_seed(4)
+    R, S = 16, 8
+    c, r = (torch.randn(R, 3, generator=g) * 0.2).cuda(), torch.randn(R, 3, generator=g).cuda()
+    d = ((torch.rand(R, S, generator=g) + torch.arange(S)) / S * 2 + 0.4).cuda()
+    params = [p for n, p in net.named_parameters() if n != 'progress']
+    net.zero_grad()
+    net.forward_samples(opt, c[None], r[None], d[None, :, :, None])['rgb_samples'].sum().backward()
+    ref = [p.grad.clone() for p in params]
+    net.zero_grad()
+    a = net.forward_samples(opt, c[None], r[None], d[None, :, :, None])
+    eng = bg_nerf.SceneEngine(net, lr=0.0)
+    eng.forward_backward(c * 2.0, r, d, torch.rand(R, 3, generator=g).cuda())
+    a['rgb_samples'].sum().backward()
+    for p, g0 in zip(params, ref):
+        assert_close(p.grad, g0.cpu(), rtol=1e-4, scaled=1e-5, name='autograd pass around an engine pass')
 
 
 def test_scene_unsupported_architecture_is_refused():
@@ -492,6 +527,21 @@ def test_depth_consistency_loss_through_the_hip_render_path():
     assert torch.isfinite(loss) and float(loss) > 0 and stats['nbr_px_sampling'] == N
     loss.backward()
     assert poses.grad is None                                   # pseudo ground truth and virtual pose use detached poses
+    for net in (sr.nerf, sr.nerf_fine):
+        gmax = max(float(p.grad.abs().max()) for n, p in net.named_parameters() if n != 'progress')
+        assert np.isfinite(gmax) and gmax > 0
+    # w = 1.0: the virtual view IS the reference view, every point stays in bounds, so the reference-view render (grad
+    # enabled, depth not detached - as in the reference), the no_grad visibility render and the virtual-view render all run
+    # at the same (R, S) before one backward
+    for net in (sr.nerf, sr.nerf_fine):
+        net.zero_grad()
+    loss1, stats1 = bg_losses.depth_consistency_loss(sr, opt, poses, intr, H, W, (0.5, 3.0), iteration=900, id_self=1,
+                                                     pixels_ref=pix, w=1.0)
+    assert torch.isfinite(loss1) and stats1['nbr_px_sampling'] == N
+    # ... summed with a photometric render of the same number of rays and samples (one backward for both)
+    ret = sr.render(opt, poses[1:2].detach(), H, W, intr[1:2], pixels=pix, depth_range=(0.5, 3.0), iter=900, mode='train')
+    photo = bg_nerf.photometric_loss(ret['rgb'], torch.rand(1, N, 3, generator=g).cuda())
+    (loss1 + photo).backward()
     for net in (sr.nerf, sr.nerf_fine):
         gmax = max(float(p.grad.abs().max()) for n, p in net.named_parameters() if n != 'progress')
         assert np.isfinite(gmax) and gmax > 0

@@ -246,3 +246,28 @@ def test_step_with_no_sample_inside_the_box_is_finite_and_leaves_the_data_gradie
     assert torch.equal(unpack_rgbnet(eng.flat.view('rgbnet'))[1][0].cpu(), P['rgbnet'][1][0])
     assert float((eng.k0_cl - k0_before).abs().max()) <= 0.1 * 1.0001
     assert int(eng.k0_touched.sum()) == 0
+
+
+def test_engine_with_capacity_below_the_sample_count_truncates_safely():
+    """TrainEngine(capacity=...) smaller than the step's in-bbox sample count: the sampler clamps the per-ray ranges, so
+    the whole fused step (forward, backward, optimiser) runs on the truncated sample list, stays finite, and the rays in
+    front of the cut render exactly as in an untruncated run."""
+    d = load('forward_g24_s10.npz')
+    ray_idx = torch.tensor(d['ray_idx'], dtype=torch.int32, device='cuda')
+    jitter = torch.tensor(d['jitter'], device='cuda')
+    full, _ = build_engine(d)
+    full.zero_grads()
+    full.render_and_grads(ray_idx, jitter, int(d['global_step']))
+    M = int(full.ws.count.item())
+    cap = max(full.N, M // 2)
+    eng, _ = build_engine(d, capacity=cap)
+    eng.zero_grads()
+    eng.train_step(ray_idx, jitter, int(d['global_step']))
+    torch.cuda.synchronize()
+    assert int(eng.ws.count.item()) == cap < M
+    rs = full.ws.ray_start.cpu().numpy()
+    whole = np.nonzero(rs[1:] <= cap)[0]
+    assert len(whole) > 0
+    assert torch.equal(eng.ws.rgb_marched[whole], full.ws.rgb_marched[whole])
+    for t in (eng.k0_cl, eng.flat.data, eng.se3, eng.ws.rgb_marched):
+        assert torch.isfinite(t).all()
