@@ -26,6 +26,7 @@ enum PPOption {
   PP_OPT_NERF_TN_WGS,          // scene branch: row splits of the fp32 weight-gradient kernel
   PP_OPT_NERF_BN,              // scene branch: 256 selects the 128 x 256 tile of the fp32 NT GEMM
   PP_OPT_NERF_PLANES,          // scene branch: 1 = activations travel as pre-split fp16 hi / lo planes (pp_gemm_planes.h)
+  PP_OPT_SDF_INDEX_EXACT,      // 1: exact voxel indices in the custom SDF sampler; 0 (default): the reference's fp32 flat index
   PP_OPT_COUNT
 };
 int pp_opt(int id);
@@ -58,6 +59,7 @@ struct SceneDev {
   int S;
   float out_range;
   int C, Lp, Lv;
+  int flat_f32;   // custom SDF sampler: form the flat voxel index in fp32 as the reference does (only differs above 2^24 voxels)
 };
 
 static inline SceneDev pp_scene_dev(const pp_scene* s) {
@@ -65,6 +67,10 @@ static inline SceneDev pp_scene_dev(const pp_scene* s) {
   for (int i = 0; i < 3; ++i) { d.mn[i] = s->xyz_min[i]; d.mx[i] = s->xyz_max[i]; d.sz[i] = s->size[i]; }
   d.voxel = s->voxel_size; d.stepsize = s->stepsize; d.near_ = s->near_clip; d.far_ = s->far_clip; d.bg = s->bg;
   d.S = s->n_samples; d.out_range = s->out_range; d.C = s->k0_dim; d.Lp = s->pos_pe; d.Lv = s->view_pe;
+  // lib/voxurf_coarse.py:632-647 computes `iz * IW * IH + iy * IW + ix` on FLOAT tensors before .long(): beyond 2^24 voxels
+  // (grids above 256^3) odd flat indices are not representable and round to a neighbouring voxel.  Reproduced by default
+  // for parity (SURVEY 8a parity hazards); option sdf_index_exact = 1 gives the exact index.
+  d.flat_f32 = ((long long)s->size[0] * s->size[1] * s->size[2] > (1ll << 24)) && pp_opt(PP_OPT_SDF_INDEX_EXACT) == 0;
   return d;
 }
 

@@ -32,7 +32,16 @@ __device__ __forceinline__ void tri_gather(const SceneDev& sc, const float* __re
     int ix = (c & 4) ? t.i1[0] : t.i0[0];
     int iy = (c & 2) ? t.i1[1] : t.i0[1];
     int iz = (c & 1) ? t.i1[2] : t.i0[2];
-    S[c] = grid[((size_t)ix * Y + iy) * Z + iz];
+    size_t flat = ((size_t)ix * Y + iy) * Z + iz;
+    if (sc.flat_f32) {
+      // the reference's fp32 index arithmetic, left to right: ((x * Z) * Y + y * Z) + z, each step rounded to fp32, then
+      // truncated (.long()); clamped to the grid (the reference's gather would fault on the one index that rounds past it)
+      const float f = __fadd_rn(__fadd_rn(__fmul_rn(__fmul_rn((float)ix, (float)Z), (float)Y), __fmul_rn((float)iy, (float)Z)), (float)iz);
+      const size_t total = (size_t)sc.sz[0] * Y * Z;
+      flat = (size_t)(long long)f;
+      if (flat >= total) flat = total - 1;
+    }
+    S[c] = grid[flat];
   }
 }
 

@@ -65,3 +65,10 @@ def step_randomness(n_total_rays, n_rand, seed):
 def se3_perturbation(n_views, std=1e-2, seed=778):
     rng = np.random.RandomState(seed)
     return (rng.randn(n_views, 6) * std).astype(np.float32)
+
+
+def voxel_id_grid(shape):
+    """Deterministic [1,1,X,Y,Z] fp32 grid whose value identifies the voxel (flat index mod 4099, fp32-exact): a lookup
+    that lands on a neighbouring voxel is visible.  Shared by oracle/make_golden.py (flatindex fixture) and the tests."""
+    n = int(shape[0]) * int(shape[1]) * int(shape[2])
+    return (np.arange(n, dtype=np.int64) % 4099).astype(np.float32).reshape(1, 1, *[int(v) for v in shape])

@@ -77,3 +77,16 @@ def assert_mostly_close(a, b, rtol, scaled, name='', outlier_frac=0.03, outlier_
     bad = (err > rtol * np.abs(b) + scaled * mx).reshape(a.shape[0], -1).any(axis=1)
     assert bad.mean() <= outlier_frac, (f'{name}: {bad.sum()}/{bad.size} rows miss the tight tolerance '
                                         f'(max abs err {err.max():.3e}, max |ref| {mx:.3e})')
+
+
+def assert_close_but(a, b, rtol, atol, name, frac=1e-3, loose_atol=5e-4):
+    """Per-sample quantities at the large grids: all entries within `loose_atol`, and all but a fraction `frac` within the
+    stated tight tolerance (the NeuS alpha is a quotient of sigmoid differences; where sigma(prev / s) is tiny, fp32
+    cancellation leaves 1e-4-level absolute noise on a handful of the ~1e5 samples, in the reference's own fp32 as well)."""
+    a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, dtype=np.float64)
+    assert a.shape == b.shape, f'{name}: shape {a.shape} vs {b.shape}'
+    err = np.abs(a - b)
+    assert err.max() <= loose_atol + rtol * np.abs(b).max(), f'{name}: max abs err {err.max():.3e}'
+    bad = err > atol + rtol * np.abs(b)
+    assert bad.mean() <= frac, f'{name}: {bad.sum()}/{a.size} outside rtol {rtol} / atol {atol} (max abs err {err.max():.3e})'

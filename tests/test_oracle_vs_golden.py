@@ -144,3 +144,32 @@ def test_alpha2weight_known_answers():
     # ray 0 by hand: back=.5*.25=.125; i=1: g=2*.5-.125/.5=.75, back=.125+2*.25=.625; i=0: g=1-.625/.5=-.25
     assert_close(g[:2], [-0.25, 0.75], rtol=1e-5)
     assert g[3] == 0 and g[4] == 0            # beyond the early stop: no gradient
+
+
+def test_custom_sampler_flat_index_is_formed_in_fp32_like_the_reference():
+    """Parity hazard: lib/voxurf_coarse.py:632-647 computes `iz * IW * IH + iy * IW + ix` on FLOAT tensors before .long().
+    Above 2^24 voxels (any grid beyond 256^3, e.g. BASELINE config 5's 320^3) odd flat indices are not representable in
+    fp32 and the gather reads a neighbouring voxel.  The fixture is the reference's own grid_sample_3d on a
+    264 x 256 x 260 grid whose value identifies the voxel; the oracle (and through it the HIP kernel, tests/test_hip_configs.py
+    at 320^3) reproduces it exactly - the reference's behaviour is the contract, option sdf_index_exact = 1 is the fix."""
+    from poseprobe_amd import synthetic as syn
+    d = load('flatindex_264.npz')
+    shape = [int(v) for v in d['shape']]
+    grid = torch.from_numpy(syn.voxel_id_grid(shape))
+    pts01 = torch.tensor(d['pts01'])
+    optical = (pts01.flip(-1) * 2 - 1).view(1, 1, 1, -1, 3)
+    got = O.trilinear_custom(grid, optical).reshape(-1)
+    assert np.array_equal(got.numpy(), d['value'])
+    # the first half of the points sit on voxel centres: the value read names the voxel that was actually fetched
+    n = pts01.shape[0] // 2
+    X, Y, Z = shape
+    idx = torch.round(pts01[:n] * (torch.tensor([X, Y, Z]) - 1)).long()
+    flat = (idx[:, 0] * Y + idx[:, 1]) * Z + idx[:, 2]
+    exact = (flat % 4099).float()
+    below, above = flat < 2 ** 24, flat >= 2 ** 24
+    assert below.any() and above.any()
+    hit = torch.isclose(torch.tensor(d['value'][:n]), exact, atol=0.51)     # centre weights are 1 up to fp32 rounding
+    assert bool(hit[below].all()), 'below 2^24 voxels every lookup reads its own voxel'
+    assert not bool(hit[above].all()), 'above 2^24 voxels the reference reads neighbouring voxels for odd flat indices'
+    odd = (flat % 2 == 1) & above
+    assert bool((~hit[odd]).all()) and bool(hit[above & ~odd].all())
