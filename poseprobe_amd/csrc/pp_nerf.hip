@@ -21,6 +21,8 @@
 #include "pp_common.h"
 #include "pp_gemm.h"
 #include "pp_gemm_split.h"
+#include "pp_gemm_planes.h"
+#include "pp_mlp_fused.h"      // pp_fused_wgs(): number of CUs
 
 #define NERF_L3D 10
 #define NERF_LV 4
@@ -61,7 +63,8 @@ extern "C" int pp_nerf_layout(int64_t* offsets) {
 // activations kept for the backward pass; rows = samples
 // mx: largest magnitudes of the GEMM operands for the split-precision path (pp_gemm_split.h); slots below
 // bits[l]: ReLU mask of layer l's output, one bit per activation, 32 bytes per sample (layout: pp_gemm.h gemm_epilogue)
-struct NerfActs { float* enc; float* a[8]; float* h; float* raw; float* mx; uint16_t* bits[8]; };
+// wimg[l]: the layer's weights as split-precision LDS images (pp_gemm_planes.h), rebuilt by every forward pass
+struct NerfActs { float* enc; float* a[8]; float* h; float* raw; float* mx; uint16_t* bits[8]; _Float16* wimg[8]; };
 enum { MX_ENC = 0, MX_A0 = 1 /* .. MX_A0 + 7 */, MX_DH = 9, MX_P = 10, MX_DY6 = 11 /* dY6 .. dY0 = 11 .. 17 */, MX_DHSUM = 18,
        MX_W0 = 32 /* .. 39 */, MX_R0 = 40, MX_SLOTS = 64 };
 static NerfActs nerf_acts(float* base, int64_t M) {
@@ -73,11 +76,19 @@ static NerfActs nerf_acts(float* base, int64_t M) {
   A.raw = p; p += M;
   A.mx = p; p += MX_SLOTS;
   for (int l = 0; l < 8; ++l) { A.bits[l] = reinterpret_cast<uint16_t*>(p); p += (M + 127) / 128 * 128 * 8; }
+  for (int l = 0; l < 8; ++l) { A.wimg[l] = reinterpret_cast<_Float16*>(p); p += 256 * NERF_IN_LD[l]; }   // hi + lo halfs = 4 B per weight
   return A;
 }
-static int64_t nerf_acts_floats(int64_t M) { return M * (64 + 256 * 6 + 320 + 288 + 128 + 1) + MX_SLOTS + (M + 127) / 128 * 128 * 64; }
+static const int64_t NERF_WIMG_FLOATS = 256 * (64 + 256 * 6 + 320);
+static int64_t nerf_acts_floats(int64_t M) {
+  return M * (64 + 256 * 6 + 320 + 288 + 128 + 1) + MX_SLOTS + (M + 127) / 128 * 128 * 64 + NERF_WIMG_FLOATS;
+}
 static const int64_t NERF_WT_FLOATS = 5 * 65536 + 320 * 256 + 256 * 288 + 64 * 256 + 288 * 128;
-static int64_t nerf_scratch_floats(int64_t M, int64_t R) { return M * (320 * 2 + 64 * 2) + R * (128 + 32) + NERF_WT_FLOATS; }
+// images of the transposed weights for the data-gradient GEMMs: R0^T (K = 128), W7^T (K = 288), W1^T .. W6^T (K = 256)
+static const int64_t NERF_WTIMG_FLOATS = 256 * (128 + 288 + 6 * 256);
+static int64_t nerf_scratch_floats(int64_t M, int64_t R) {
+  return M * (320 * 2 + 64 * 2) + R * (128 + 32) + NERF_WT_FLOATS + NERF_WTIMG_FLOATS;
+}
 
 extern "C" int pp_nerf_workspace(int64_t n_samples, int64_t n_rays, int64_t* acts_floats, int64_t* scratch_floats) {
   PP_REQUIRE(acts_floats && scratch_floats && n_samples > 0 && n_rays > 0, "bad arguments");
@@ -540,15 +551,25 @@ static int nerf_wide_tiles() { return pp_opt(PP_OPT_NERF_BN) == 256; }
 #define NERF_SPLIT (pp_opt(PP_OPT_NERF_SPLIT) == 1)
 #define NERF_SPLIT_TN (pp_opt(PP_OPT_NERF_SPLIT_TN) == 1)
 #define NERF_BITMASK (pp_opt(PP_OPT_NERF_BITMASK) == 1)
+//   nerf_planes        256-wide layers on the second-generation kernel (pp_gemm_planes.h: weights pre-split into LDS images once
+//                      per pass, 128 x 256 tile on eight wavefronts); needs nerf_split and nerf_bitmask; 0 = first generation
+#define NERF_PLANES (pp_opt(PP_OPT_NERF_PLANES) == 1 && NERF_SPLIT && NERF_BITMASK)
 
 template <int EPI>
 static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, int K, int Nout, const float* bias,
                       const float* mask, int ldm, float* C, int ldc, const int32_t* count, int rows,
                       const float* a_max = nullptr, const float* w_max = nullptr, float* c_max = nullptr,
-                      uint16_t* bits = nullptr) {
+                      uint16_t* bits = nullptr, const _Float16* wimg = nullptr) {
   const int tiles = pp_div_up(rows, NERF_BM);
   dim3 b(256);
   if (!NERF_BITMASK) bits = nullptr;
+  if (wimg && bits && EPI != EPI_PLAIN && Nout == 256 && (K & 31) == 0 && a_max && w_max && NERF_PLANES) {
+    const int cus = pp_fused_wgs();
+    constexpr int E = (EPI == EPI_PLAIN) ? EPI_MASK : EPI;
+    hipLaunchKernelGGL((k_gemm256p<E>), dim3(tiles < cus ? tiles : cus), dim3(512), 0, st, A, lda, wimg, K, bias, C, ldc, count, rows,
+                       a_max, w_max, c_max, bits);
+    return;
+  }
   if (NERF_SPLIT && a_max && w_max) {
     if (Nout <= 64) {
       dim3 g(tiles < 2 * NERF_GEMM_WGS ? tiles : 2 * NERF_GEMM_WGS, 1);
@@ -616,6 +637,14 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
     J.src[8] = params + L.r0; J.n[8] = 128 * 288;
     hipLaunchKernelGGL(k_nerf_wmax, dim3(32, 9), dim3(256), 0, st, J, mx);
     hipLaunchKernelGGL(k_nerf_enc_bound, dim3(pp_div_up(n_rays, 4)), dim3(256), 0, st, center, ray, depth, n_rays, n_samples, mx);
+    if (NERF_PLANES) {
+      PlanePackJobs P;
+      P.n = 8;
+      for (int l = 0; l < 8; ++l) {
+        P.src[l] = params + L.w[l]; P.dst[l] = A.wimg[l]; P.ld[l] = NERF_IN_LD[l]; P.K[l] = NERF_IN_LD[l]; P.mx_slot[l] = MX_W0 + l;
+      }
+      hipLaunchKernelGGL(k_pack_planes, dim3(16, 8), dim3(256), 0, st, P, mx);
+    }
   }
   hipLaunchKernelGGL(k_nerf_encode, dim3(pp_div_up(M, 4)), dim3(256), 0, st, center, ray, depth, bands, M,
                      n_samples, A.enc, A.a[3], A.a[7]);
@@ -623,7 +652,7 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
   for (int l = 0; l < 8; ++l) {
     nerf_gemm<EPI_RELU>(st, in, NERF_IN_LD[l], params + L.w[l], NERF_IN_LD[l], NERF_IN_LD[l], 256, params + L.b[l], nullptr, 0,
                         A.a[l], NERF_OUT_LD[l], count, M, mx ? mx + (l == 0 ? MX_ENC : MX_A0 + l - 1) : nullptr,
-                        mx ? mx + MX_W0 + l : nullptr, mx ? mx + MX_A0 + l : nullptr, A.bits[l]);
+                        mx ? mx + MX_W0 + l : nullptr, mx ? mx + MX_A0 + l : nullptr, A.bits[l], A.wimg[l]);
     in = A.a[l];
   }
   hipLaunchKernelGGL(k_nerf_density_fwd, dim3(pp_div_up(M, 4)), dim3(256), 0, st, A.a[6], params + L.wd, params + L.bd, M,
@@ -660,6 +689,10 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
     for (int l = 0; l < 8; ++l) { WT[l] = p; p += (l == 7) ? 256 * 288 : 256 * NERF_IN_LD[l]; }
   }
   float* R0T = WT[7] + 256 * 288;                  // [288][128]
+  _Float16* r0t_img = reinterpret_cast<_Float16*>(wt + NERF_WT_FLOATS);
+  _Float16* wt7_img = r0t_img + 2 * 256 * 128;
+  _Float16* wt_img[7];
+  for (int l = 1; l <= 6; ++l) wt_img[l] = wt7_img + 2 * 256 * 288 + (size_t)(l - 1) * 2 * 256 * 256;
   dim3 b(256);
   // transposed weights for the data-gradient GEMMs (2 MB, L2 resident)
   {
@@ -676,6 +709,15 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
   // split-precision path: operand maxima of the gradient tensors are recorded by their producers (slots MX_DH .. MX_DHSUM)
   float* mx = NERF_SPLIT ? A.mx : nullptr;
   if (mx) hipMemsetAsync(mx + MX_DH, 0, (MX_DHSUM - MX_DH + 1) * sizeof(float), st);
+  const bool planes = mx && NERF_PLANES;
+  if (planes) {
+    PlanePackJobs P;
+    P.n = 8;
+    P.src[0] = R0T; P.dst[0] = r0t_img; P.ld[0] = 128; P.K[0] = 128; P.mx_slot[0] = MX_R0;
+    P.src[7] = WT[7]; P.dst[7] = wt7_img; P.ld[7] = 288; P.K[7] = 288; P.mx_slot[7] = MX_W0 + 7;
+    for (int l = 1; l <= 6; ++l) { P.src[l] = WT[l]; P.dst[l] = wt_img[l]; P.ld[l] = 256; P.K[l] = 256; P.mx_slot[l] = MX_W0 + l; }
+    hipLaunchKernelGGL(k_pack_planes, dim3(16, 8), dim3(256), 0, st, P, mx);
+  }
   auto slot = [&](int i) -> float* { return mx ? mx + i : nullptr; };
 
   // colour head
@@ -688,12 +730,12 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
                        slot(MX_R0), nullptr);
   // last feature layer: columns 0..255 through the colour head, column 256 from the density
   nerf_gemm<EPI_MASK>(st, dH, 128, R0T, 128, 128, 256, nullptr, A.a[7], 288, P, 288, count, M, slot(MX_DH), slot(MX_R0),
-                      slot(MX_P), A.bits[7]);
+                      slot(MX_P), A.bits[7], planes ? r0t_img : nullptr);
   hipLaunchKernelGGL(k_nerf_density_bwd, dim3(pp_div_up(M, NERF_DSTRIP)), dim3(1024), 0, st, A.a[6], A.raw, g_density_samples, M, P,
                      params_grad + L.wd, params_grad + L.bd, slot(MX_P));
   nerf_gemm_tn(st, P, 288, 256, A.a[6], 256, 256, params_grad + L.w[7], params_grad + L.b[7], count, M, slot(MX_P), slot(MX_A0 + 6));
   nerf_gemm<EPI_MASK>(st, P, 288, WT[7], 288, 288, 256, nullptr, A.a[6], 256, Q, 256, count, M, slot(MX_P), slot(MX_W0 + 7),
-                      slot(MX_DY6), A.bits[6]);
+                      slot(MX_DY6), A.bits[6], planes ? wt7_img : nullptr);
   float* cur = Q;
   float* nxt = P;
   for (int l = 6; l >= 1; --l) {                   // cur = d(pre-activation of layer l), [M][256]
@@ -702,7 +744,7 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
     nerf_gemm_tn(st, cur, 256, 256, x, ldx, NERF_IN_LD[l], params_grad + L.w[l], params_grad + L.b[l], count, M,
                  slot(MX_DY6 + 6 - l), slot(MX_A0 + l - 1));
     nerf_gemm<EPI_MASK>(st, cur, 256, WT[l], 256, 256, 256, nullptr, x, ldx, nxt, 256, count, M, slot(MX_DY6 + 6 - l),
-                        slot(MX_W0 + l), slot(MX_DY6 + 7 - l), A.bits[l - 1]);
+                        slot(MX_W0 + l), slot(MX_DY6 + 7 - l), A.bits[l - 1], planes ? wt_img[l] : nullptr);
     if (l == 4)                                    // skip columns: gradient of the encoding, no activation in between
       nerf_gemm<EPI_PLAIN>(st, cur, 256, WT[4] + 256 * 256, 256, 256, 64, nullptr, nullptr, 0, dEncS, 64, count, M,
                            slot(MX_DY6 + 2), slot(MX_W0 + 4), nullptr);
