@@ -498,33 +498,138 @@ class TrainEngine:
               for i in range(5)]
         self.load_reference_params(sd['k0.grid'], sd['sdf.grid'], sd['sdf_alpha'], sd['sdf_beta'], rg, wp)
 
+    # ---- optimiser state in the reference's layout ---------------------------------------------------------------------
+    # lib/recon_scene.py:779-791 stores `self.optimizer.state_dict()` of lib.utils.Adam (a torch.optim.Optimizer): 'state'
+    # {param index: {'step', 'exp_avg', 'exp_avg_sq'}} + 'param_groups' [{'name', 'lr', 'params': [indices], ...}], one group
+    # per `lrate_<name>` key, parameters in `module.parameters()` order (warp_network starts with its gradient-less
+    # `progress`, which never gets a state entry).
+    GROUPS = ('sdf_alpha', 'sdf_beta', 'k0', 'rgbnet', 'warp_network')
+
+    def _group_tensors(self, which):
+        """{group name: list of tensors in the reference's parameter order and logical shapes} for 'm' or 'v'."""
+        P = self.flat
+        ab = P.view('sdf_ab', which)
+        k0 = {'m': self.k0_m, 'v': self.k0_v}[which]
+        rg = [t for Wb in unpack_rgbnet(P.view('rgbnet', which)) for t in Wb]
+        wp = [t for Wb in unpack_warp(P.view('warp', which)) for t in Wb]
+        return {'sdf_alpha': [ab[0:1]], 'sdf_beta': [ab[1:2]], 'k0': [self.k0_reference_layout(k0)], 'rgbnet': rg,
+                'warp_network': [None] + wp}                       # None = warp_network.progress (no state)
+
+    def optimizer_state_dict(self):
+        c = lambda t: t.detach().clone().cpu().contiguous()
+        m, v = self._group_tensors('m'), self._group_tensors('v')
+        lr = {'sdf_alpha': self.lr['sdf_ab'], 'sdf_beta': self.lr['sdf_ab'], 'k0': self.lr['k0'], 'rgbnet': self.lr['rgbnet'],
+              'warp_network': self.lr['warp']}
+        state, groups, idx = {}, [], 0
+        for name in self.GROUPS:
+            ids = []
+            for tm, tv in zip(m[name], v[name]):
+                if tm is not None and self.n_step > 0:
+                    state[idx] = {'step': self.n_step, 'exp_avg': c(tm), 'exp_avg_sq': c(tv)}
+                ids.append(idx)
+                idx += 1
+            groups.append({'params': ids, 'lr': float(lr[name]), 'name': name, 'betas': (0.9, 0.99), 'eps': 1e-8,
+                           'weight_decay': 0, 'amsgrad': False})
+        return {'state': state, 'param_groups': groups}
+
+    def pose_optimizer_state_dict(self):
+        c = lambda t: t.detach().clone().cpu()
+        state = {0: {'step': self.n_step, 'exp_avg': c(self.se3_m), 'exp_avg_sq': c(self.se3_v)}} if self.n_step > 0 else {}
+        return {'state': state, 'param_groups': [{'params': [0], 'lr': float(self.lr_pose), 'betas': (0.9, 0.999), 'eps': 1e-8,
+                                                  'weight_decay': 0, 'amsgrad': False}]}
+
+    def load_optimizer_state_dict(self, sd, pose_sd=None):
+        """Reads the reference's (or this engine's) torch-Adam layout into the flat moment buffers; groups are matched by
+        `name`, parameters by position inside their group.  Groups that are absent keep zero moments."""
+        d = lambda t: torch.as_tensor(t, dtype=torch.float32).to(self.dev)
+        state = sd['state']
+        m, v = self._group_tensors('m'), self._group_tensors('v')
+        steps = []
+        with torch.no_grad():
+            for t in (self.k0_m, self.k0_v, self.flat.m, self.flat.v):
+                t.zero_()
+            for grp in sd['param_groups']:
+                name = grp.get('name')
+                if name not in m:
+                    continue
+                if len(grp['params']) != len(m[name]):
+                    raise ValueError(f"optimizer group '{name}': {len(grp['params'])} parameters, expected {len(m[name])}")
+                for i, tm, tv in zip(grp['params'], m[name], v[name]):
+                    st = state.get(i, state.get(str(i)))
+                    if st is None or tm is None:
+                        continue
+                    tm.copy_(d(st['exp_avg']).reshape(tm.shape))
+                    tv.copy_(d(st['exp_avg_sq']).reshape(tv.shape))
+                    steps.append(int(st['step']))
+                key = {'sdf_alpha': 'sdf_ab', 'sdf_beta': 'sdf_ab', 'warp_network': 'warp'}.get(name, name)
+                self.lr[key] = float(grp['lr'])
+            if pose_sd is not None and pose_sd.get('state'):
+                st = pose_sd['state'].get(0, pose_sd['state'].get('0'))
+                self.se3_m.copy_(d(st['exp_avg']))
+                self.se3_v.copy_(d(st['exp_avg_sq']))
+                self.lr_pose = float(pose_sd['param_groups'][0]['lr'])
+        if steps:
+            if len(set(steps)) != 1:
+                raise ValueError(f'optimizer state with differing step counts {sorted(set(steps))}: the fused Adam keeps one')
+            self.n_step = steps[0]
+
+    def model_kwargs(self):
+        """Constructor arguments of the drop-in `Voxurf` for this engine's configuration, as plain Python values (a checkpoint
+        holding them loads weights-only; utils.load_model rebuilds the module from them)."""
+        cfg = self.cfg
+        rs = [float(cfg.out_range)] * 3
+        return {'xyz_min': [float(x) for x in cfg.xyz_min], 'xyz_max': [float(x) for x in cfg.xyz_max],
+                'num_voxels': int(cfg.num_voxels), 'num_voxels_base': int(cfg.num_voxels), 'alpha_init': 1e-2,
+                'rgbnet_dim': int(cfg.k0_dim), 'rgbnet_direct': True, 'rgbnet_depth': 4, 'rgbnet_width': 128,
+                'posbase_pe': int(cfg.posbase_pe), 'viewbase_pe': int(cfg.viewbase_pe), 'geo_rgb_dim': 3,
+                's_ratio': float(cfg.s_ratio), 's_start': float(cfg.s_start), 'step_start': float(cfg.step_start),
+                'barf_c2f': None if cfg.barf_c2f is None else [float(x) for x in cfg.barf_c2f], 'N_iters': int(cfg.N_iters),
+                'i_train': list(range(self.V)), 'HW': [[int(self.H), int(self.W)]] * self.V, 'camera_noise': 0.0,
+                'range_shape': rs, 'rect_size': rs}
+
     def save_checkpoint(self, path, global_step):
-        """Keys as the reference writes them (`global_step`, `current_pose`, `model_state_dict`, `optimizer_state_dict`);
-        the optimiser entry holds this engine's flat Adam state (the reference stores a torch optimizer state_dict there)."""
+        """The reference's `last_ckpt.tar` (lib/recon_scene.py:779-791): `global_step`, `current_pose`, `model_kwargs`,
+        `MaskCache_kwargs`, `model_state_dict`, `optimizer_state_dict`, `optimizer_pose_state_dict` - the optimiser entries in
+        torch-Adam layout - plus this engine's pose parametrisation (`se3_refine`, `w2c_init`) and schedule state."""
         ops.pose_fwd(self.se3, self.w2c_init, self.refine_mask, self.w2c, self.c2w, self.jac)
         c = lambda t: t.detach().clone().cpu()
-        opt = {'format': 'poseprobe_amd.TrainEngine/1', 'n_step': self.n_step, 'lr': dict(self.lr), 'lr_pose': self.lr_pose,
-               'k0.exp_avg': c(self.k0_m), 'k0.exp_avg_sq': c(self.k0_v), 'flat.exp_avg': c(self.flat.m),
-               'flat.exp_avg_sq': c(self.flat.v), 'se3.exp_avg': c(self.se3_m), 'se3.exp_avg_sq': c(self.se3_v)}
-        torch.save({'global_step': int(global_step), 'current_pose': [c(p) for p in self.w2c],
+        cfg = self.cfg
+        torch.save({'global_step': int(global_step), 'current_pose': c(self.w2c),
+                    'model_kwargs': self.model_kwargs(),
+                    'MaskCache_kwargs': {'xyz_min': [float(x) for x in cfg.xyz_min], 'xyz_max': [float(x) for x in cfg.xyz_max],
+                                         'act_shift': float(np.log(1 / (1 - 1e-2) - 1)), 'voxel_size_ratio': 1.0, 'nearest': False},
+                    'model_state_dict': self.model_state_dict(), 'optimizer_state_dict': self.optimizer_state_dict(),
+                    'optimizer_pose_state_dict': self.pose_optimizer_state_dict(),
                     'se3_refine': c(self.se3), 'w2c_init': c(self.w2c_init),
-                    'model_state_dict': self.model_state_dict(), 'optimizer_state_dict': opt}, path)
+                    'engine': {'format': 'poseprobe_amd.TrainEngine/2', 'n_step': self.n_step, 'lr': dict(self.lr),
+                               'lr_pose': self.lr_pose}}, path)
 
     def load_checkpoint(self, path, reload_optimizer=True):
-        """-> global_step.  Accepts checkpoints written by save_checkpoint and, for the model part, any checkpoint whose
-        `model_state_dict` uses the reference's names (weights_only load: nothing in the file is executed)."""
-        ck = torch.load(path, map_location='cpu', weights_only=True)
+        """-> global_step.  Accepts this engine's files and reference `last_ckpt.tar` files (model under the reference's names,
+        optimiser in torch-Adam layout).  Weights-only load (numpy arrays in `model_kwargs` admitted): nothing is executed."""
+        from .utils import load_checkpoint_file
+        ck = load_checkpoint_file(path)
         self.load_model_state_dict(ck['model_state_dict'])
-        d = lambda t: t.to(self.dev)
+        d = lambda t: torch.as_tensor(t, dtype=torch.float32).to(self.dev)
         if 'se3_refine' in ck:
             self.se3.copy_(d(ck['se3_refine']))
             self.w2c_init.copy_(d(ck['w2c_init']))
+        elif 'current_pose' in ck:                          # a reference file: start from its poses, refinement at zero
+            cp = ck['current_pose']
+            cp = torch.stack([torch.as_tensor(p) for p in cp]) if isinstance(cp, (list, tuple)) else torch.as_tensor(cp)
+            self.w2c_init.copy_(d(cp)[:, :3, :4])
+            self.se3.zero_()
         opt = ck.get('optimizer_state_dict', {})
-        if reload_optimizer and opt.get('format') == 'poseprobe_amd.TrainEngine/1':
+        if reload_optimizer and opt.get('format') == 'poseprobe_amd.TrainEngine/1':     # round-1 files
             self.n_step, self.lr, self.lr_pose = int(opt['n_step']), dict(opt['lr']), float(opt['lr_pose'])
             self.k0_m.copy_(d(opt['k0.exp_avg'])); self.k0_v.copy_(d(opt['k0.exp_avg_sq']))
             self.flat.m.copy_(d(opt['flat.exp_avg'])); self.flat.v.copy_(d(opt['flat.exp_avg_sq']))
             self.se3_m.copy_(d(opt['se3.exp_avg'])); self.se3_v.copy_(d(opt['se3.exp_avg_sq']))
+        elif reload_optimizer and 'param_groups' in opt:
+            self.load_optimizer_state_dict(opt, ck.get('optimizer_pose_state_dict'))
+            eng = ck.get('engine')
+            if eng is not None:
+                self.n_step, self.lr, self.lr_pose = int(eng['n_step']), dict(eng['lr']), float(eng['lr_pose'])
         self.zero_grads()
         return int(ck.get('global_step', 0))
 

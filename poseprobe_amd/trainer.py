@@ -37,10 +37,32 @@ def c2f_progress(iteration_nerf, max_iter):
     return iteration_nerf / max_iter
 
 
+def active_views(global_step, n_views, incremental_step, incremental=True, start=2):
+    """Number of views in play at `global_step`: the incremental schedule of lib/recon_scene.py:552-576 starts from the first
+    two views and takes in one more whenever the step count reaches a multiple of `cfg.camera.incremental_step` (the
+    check runs before the step's batch is drawn, never at step 0) until all views are in."""
+    if not incremental or incremental_step <= 0:
+        return n_views
+    return int(min(n_views, start + max(global_step, 0) // incremental_step))
+
+
+def object_phase(global_step, n_iters_object, start_object=0):
+    """The object branch is optimised while start_object <= step <= cfg_train.N_iters (lib/recon_scene.py:584)."""
+    return start_object <= global_step <= n_iters_object
+
+
 class DualBranchTrainer:
     def __init__(self, obj_engine, opt, max_iter=60000, lr=1e-3, lr_end=1e-4, ratio_start_fine=0.3, ratio_end_pose=0.3,
-                 depth_range=(0.5, 3.0), seed=0):
+                 depth_range=(0.5, 3.0), seed=0, incremental_step=0, pose_initialiser=None, pose_terms=()):
+        """incremental_step > 0: the incremental view schedule (`active_views`); a view that joins gets its initial pose from
+        `pose_initialiser(view, w2c_of_previous_view [3,4]) -> w2c [3,4]` - the reference's PnP hand-off (cv2.solvePnPRansac on
+        matcher output, lib/recon_scene.py:202-214, :276-310) plugs in here; the default is its `use_identical` variant (the
+        previous view's current pose).  pose_terms: extra pose-only loss terms mixed into the object loss as the reference
+        mixes its reprojection / near-surface terms (:616-637): callables `f(se3 [V,6] requiring grad, w2c_init, n_active)
+        -> (weight, scalar loss)`, differentiated by torch autograd through camera.current_pose_c2w."""
         self.opt, self.max_iter = opt, max_iter
+        self.incremental_step, self.pose_initialiser, self.pose_terms = incremental_step, pose_initialiser, tuple(pose_terms)
+        self.n_active = None
         self.lr, self.lr_end = lr, lr_end
         self.ratio_start_fine, self.ratio_end_pose = ratio_start_fine, ratio_end_pose
         dev = obj_engine.dev
@@ -52,25 +74,66 @@ class DualBranchTrainer:
         self.dev = dev
 
     # ---- batches (recon_scene.py:598-606 for the object branch, sampling_strategies.py:132-170 for the scene branch) ------
-    def sample_batch(self):
+    def sample_batch(self, n_active=None):
+        """Object-branch rays are a prefix of a permutation of the ACTIVE views' pixels (views 0 .. n_active - 1 are
+        contiguous in the flattened [V, H, W] order); the scene branch draws rand_rays // n_active pixels per active view."""
         e = self.joint.obj
-        n_total = e.V * e.H * e.W
+        k = e.V if n_active is None else n_active
+        n_total = k * e.H * e.W
         ray_idx = torch.randperm(n_total, device=self.dev, generator=self.gen)[:e.N].to(torch.int32)
         jitter = torch.rand(e.N, device=self.dev, generator=self.gen)
-        n_pix = self.opt.nerf.rand_rays // e.V
+        n_pix = self.opt.nerf.rand_rays // k
         flat = torch.randperm(e.H * e.W, device=self.dev, generator=self.gen)[:n_pix]
         py, px = flat // e.W, flat % e.W
-        image = e.images[:, py, px]                                    # [V, n_pix, 3] ground-truth colours at those pixels
+        image = e.images[:k, py, px]                                   # [k, n_pix, 3] ground-truth colours at those pixels
         pixels = torch.stack([px.float() + 0.5, py.float() + 0.5], dim=-1)
         return ray_idx, jitter, pixels, image
+
+    def _admit_views(self, global_step):
+        """Incremental schedule: views joining at this step start from a handed-over pose with zero refinement."""
+        e = self.joint.obj
+        k = active_views(global_step, e.V, self.incremental_step, self.incremental_step > 0)
+        if self.n_active is None:
+            self.n_active = k if self.incremental_step <= 0 else min(k, 2)
+        while self.n_active < k:
+            v = self.n_active
+            from . import ops
+            ops.pose_fwd(e.se3, e.w2c_init, e.refine_mask, e.w2c, e.c2w, e.jac)          # current pose of the previous view
+            prev = e.w2c[v - 1].detach().clone()
+            init = prev if self.pose_initialiser is None else torch.as_tensor(self.pose_initialiser(v, prev.cpu()),
+                                                                              dtype=torch.float32).to(e.dev)
+            with torch.no_grad():
+                e.w2c_init[v].copy_(init[:3, :4])
+                e.se3[v].zero_(); e.se3_m[v].zero_(); e.se3_v[v].zero_()
+            self.n_active += 1
+        return self.n_active
+
+    def _mix_pose_terms(self, k):
+        """loss += w_i * L_i(poses) for the extra pose-only terms: their se3 gradient joins the object branch's (which the
+        engine scales by loss_scale = 0.1, lib/recon_scene.py:648)."""
+        if not self.pose_terms:
+            return {}
+        e = self.joint.obj
+        se3 = e.se3.detach().clone().requires_grad_(True)
+        values, total = {}, 0.
+        for i, term in enumerate(self.pose_terms):
+            w, val = term(se3, e.w2c_init, k)
+            values[getattr(term, '__name__', f'term{i}')] = float(val.detach())
+            total = total + w * val
+        (total * e.loss_scale).backward()
+        e.se3_grad += se3.grad * e.refine_mask[:, None].to(se3.grad.dtype)
+        return values
 
     def train_step(self, global_step):
         """One iteration of the joint loop; returns (object-branch summary, scene loss)."""
         self.iteration += 1
+        k = self._admit_views(global_step)
         fine = fine_phase(global_step, self.max_iter, self.ratio_start_fine, self.nerf_fine is not None)
-        ray_idx, jitter, pixels, image = self.sample_batch()
+        ray_idx, jitter, pixels, image = self.sample_batch(k)
+        self.last_pose_terms = {}
         out = self.joint.train_step(ray_idx, jitter, global_step, pixels, image, fine=fine,
-                                    optimize_pose=pose_phase(global_step, self.max_iter, self.ratio_end_pose))
+                                    optimize_pose=pose_phase(global_step, self.max_iter, self.ratio_end_pose), n_views=k,
+                                    before_step=(lambda: self.last_pose_terms.update(self._mix_pose_terms(k))) if self.pose_terms else None)
         self.joint.scene.set_lr(scene_lr(self.iteration, self.lr, self.lr_end, self.max_iter))
         p = c2f_progress(self.iteration, self.max_iter)                # takes effect from the next iteration (renderer.py:399)
         self.nerf.progress.data.fill_(p)

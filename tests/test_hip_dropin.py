@@ -290,3 +290,38 @@ def test_directvoxgo_twin_backward_is_complete():
     for li, lin in enumerate([m.rgbnet[0], m.rgbnet[2][0], m.rgbnet[3]]):
         assert_close(c(lin.weight.grad), d[f'lf_g.rgbnet.{li}.weight'], name=f'g.rgbnet{li}.W', **tol)
         assert_close(c(lin.bias.grad), d[f'lf_g.rgbnet.{li}.bias'], name=f'g.rgbnet{li}.b', **tol)
+
+
+def test_render_viewpoints_matches_the_reference_driver(tmp_path):
+    """Full-image inference driver (lib/nvs_fun.py:39-188): two whole 32 x 32 views in 4096-ray chunks through
+    Voxurf.inference, assembled images and disparity maps against the reference's own render_viewpoints (fixture produced by
+    executing its function body), the three PSNRs it logs (2 decimals in the log), and the files it writes."""
+    import types
+    import zlib
+    from poseprobe_amd import nvs_fun
+    d = load('viewpoints_g24.npz')
+    m = make_model(d)
+    H, W = int(d['H']), int(d['W'])
+    rk = dict(near=0.24, far=4.8, bg=0, stepsize=1.5, inverse_y=True, flip_x=False, flip_y=False)
+    cfg = types.SimpleNamespace(data=types.SimpleNamespace(flip_x=False, flip_y=False))
+    nv = d['w2c'].shape[0]
+    rgbs, disps = nvs_fun.render_viewpoints(m, torch.tensor(d['w2c']), cfg, np.array([[H, W]] * nv), d['Ks'], False, rk,
+                                            gt_imgs=d['gt'], masks=d['masks'], savedir=str(tmp_path), step=7)
+    assert rgbs.shape == d['rgbs'].shape and disps.shape == d['disps'].shape
+    assert_close(rgbs, d['rgbs'], rtol=1e-4, atol=1e-5, name='images')
+    fin = np.isfinite(d['disps'])                              # rays that hit nothing have depth 0, disparity inf - in both
+    assert np.array_equal(np.isfinite(disps), fin)
+    assert_close(disps[fin], d['disps'][fin], rtol=1e-4, atol=1e-5, name='disparity maps')
+    last = nvs_fun.render_viewpoints.last['per_view']
+    got = np.array([last['psnr'], last['psnr_fore'], last['psnr_back']]).T
+    assert np.abs(got - d['psnr_logged']).max() <= 0.0051 + 1e-3, (got, d['psnr_logged'])
+    for i in range(nv):
+        for name in (f'7_{i:03d}.png', f'7_render_{i:03d}.png', f'7_gt_{i:03d}.png', f'7_{i:03d}_normal.png'):
+            raw = open(tmp_path / name, 'rb').read()
+            assert raw[:8] == b'\x89PNG\r\n\x1a\n'
+        raw = open(tmp_path / f'7_render_{i:03d}.png', 'rb').read()
+        idat = raw[raw.index(b'IDAT') + 4:raw.index(b'IEND') - 8]
+        px = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(H, 1 + 3 * W)[:, 1:].reshape(H, W, 3)
+        assert np.array_equal(px, nvs_fun.to8b(rgbs[i]))
+    with pytest.raises(NotImplementedError):
+        nvs_fun.render_viewpoints(m, torch.tensor(d['w2c']), cfg, np.array([[H, W]] * nv), d['Ks'], False, rk, eval_ssim=True)

@@ -165,3 +165,60 @@ def test_joint_step_through_rccl_on_one_rank_matches_plain():
         finals.append((eng.se3.clone().cpu(), net.flat.clone().cpu()))
     assert_close(finals[1][0], finals[0][0], rtol=0, atol=2e-4, name='se3')
     assert float((finals[1][1] - finals[0][1]).abs().gt(3e-4).float().mean()) < 0.02
+
+
+def test_trainer_incremental_views_pose_hand_off_and_loss_mixing():
+    """The trainer counterpart's control decisions (lib/recon_scene.py:552-649): views join one by one at multiples of
+    `incremental_step`, a joining view starts from a handed-over pose (default = the previous view's current pose, the
+    reference's `use_identical`; a callback stands where cv2.solvePnPRansac does), batches only touch active views, and
+    extra pose-only terms are mixed into the object loss (scaled by 0.1 with it) before the optimiser step."""
+    from poseprobe_amd import bg_nerf
+    from poseprobe_amd.trainer import DualBranchTrainer, active_views
+    assert [active_views(s, 6, 100) for s in (0, 99, 100, 250, 400, 10 ** 6)] == [2, 2, 3, 4, 6, 6]
+    assert active_views(0, 3, 0, incremental=False) == 3
+    d = load('forward_g24_s10.npz')
+    V, H, W = d['images'].shape[:3]
+    opt = bg_nerf.default_options(sample_intvs=16)
+    opt.nerf.rand_rays = 96
+    calls = []
+
+    def from_pnp(view, prev_w2c):
+        calls.append((view, prev_w2c.clone()))
+        out = prev_w2c.clone()
+        out[:, 3] += torch.tensor([0.01, -0.02, 0.03])
+        return out
+
+    def pull_to_zero(se3, w2c_init, k):
+        return 0.5, (se3[:k] ** 2).sum()
+
+    for initialiser in (None, from_pnp):
+        eng, _ = build_engine(d)
+        eng.zero_grads()
+        torch.manual_seed(3)
+        tr = DualBranchTrainer(eng, opt, max_iter=20, incremental_step=2, pose_initialiser=initialiser, pose_terms=(pull_to_zero,))
+        init_before, se3_before = eng.w2c_init.clone(), eng.se3.clone()
+        ray_idx, _, pixels, image = tr.sample_batch(2)
+        assert int(ray_idx.max()) < 2 * H * W and image.shape[0] == 2 and pixels.shape[0] == 96 // 2
+        for step in range(2):
+            tr.train_step(step)
+        assert tr.n_active == 2 and torch.equal(eng.w2c_init[2], init_before[2]) and torch.equal(eng.se3[2], se3_before[2])
+        assert not torch.equal(eng.se3[1], se3_before[1])         # an active, refined view moves
+        assert 'pull_to_zero' in tr.last_pose_terms
+        from poseprobe_amd import ops
+        ops.pose_fwd(eng.se3, eng.w2c_init, eng.refine_mask, eng.w2c, eng.c2w, eng.jac)
+        pose1 = eng.w2c[1].clone()
+        tr.train_step(2)                                         # view 2 joins
+        assert tr.n_active == 3
+        if initialiser is None:
+            assert_close(eng.w2c_init[2], pose1.cpu(), rtol=0, atol=1e-6, name='identical hand-off')
+        else:
+            assert calls and calls[-1][0] == 2
+            assert_close(calls[-1][1], pose1.cpu(), rtol=0, atol=1e-6, name='previous pose handed to the initialiser')
+            assert_close(eng.w2c_init[2][:, 3], (pose1[:, 3].cpu() + torch.tensor([0.01, -0.02, 0.03])), rtol=0, atol=1e-6, name='initialised pose')
+        assert float(eng.se3[2].abs().max()) > 0.0               # ... and is refined from its first step on
+        # the mixing itself: d(0.1 * 0.5 * |se3|^2) / d se3 on the refined views
+        eng.se3_grad.zero_()
+        tr._mix_pose_terms(3)
+        expect = 0.1 * 0.5 * 2.0 * eng.se3 * eng.refine_mask[:, None]
+        assert_close(eng.se3_grad, expect.cpu(), rtol=1e-6, atol=1e-9, name='mixed pose term')
+        eng.se3_grad.zero_()

@@ -183,6 +183,62 @@ def test_checkpoint_resume_reproduces_the_trajectory(tmp_path):
     missing, unexpected = m.load_state_dict(ck['model_state_dict'], strict=False)
     assert not unexpected, unexpected
     assert torch.equal(m.k0.grid.detach().cpu(), ck['model_state_dict']['k0.grid'])
+    # the engine's file is a reference-style last_ckpt.tar: utils.load_model rebuilds the drop-in module from its model_kwargs
+    from poseprobe_amd import utils, voxurf_coarse as Model
+    m2 = utils.load_model(Model.Voxurf, path, strict=False)
+    assert torch.equal(m2.k0.grid.detach().cpu(), ck['model_state_dict']['k0.grid'])
+    assert torch.equal(m2.rgbnet[0].weight.detach().cpu(), ck['model_state_dict']['rgbnet.0.weight'])
+    # ... and its optimiser entries load into the reference's optimiser classes (torch-Adam layout, lib/utils.py:316-362)
+    from poseprobe_amd.config import ConfigDict
+    cfg_train = ConfigDict(lrate_decay=10, lrate_sdf_alpha=1e-2, lrate_sdf_beta=1e-2, lrate_k0=1e-1, lrate_rgbnet=1e-3,
+                           lrate_warp_network=1e-3, lr_pose=1e-3, lr_pose_end=1e-4, sched_pose='ExponentialLR')
+    opt = utils.create_optimizer_or_freeze_model(m2, cfg_train, global_step=0)
+    assert [g['name'] for g in opt.param_groups] == [g['name'] for g in ck['optimizer_state_dict']['param_groups']]
+    opt.load_state_dict(ck['optimizer_state_dict'])
+    k0_state = opt.state[opt.param_groups[2]['params'][0]]
+    assert k0_state['step'] == 2 and tuple(k0_state['exp_avg'].shape) == tuple(m2.k0.grid.shape)
+    assert_close(k0_state['exp_avg'].permute(0, 2, 3, 4, 1)[0], n(b.k0_m), rtol=0, atol=0, name='k0 exp_avg through torch-Adam')
+
+
+def test_reference_layout_optimizer_state_round_trips_through_a_torch_optimizer():
+    """A reference `last_ckpt.tar` carries `optimizer.state_dict()` of lib.utils.Adam (lib/recon_scene.py:779-791).  Build
+    exactly that with the drop-in module + optimiser, step it, and read the state into a fresh engine: moments, step count and
+    learning rates arrive in the flat buffers (k0 transposed to channels-last, rgbnet W0 padded 57 -> 64)."""
+    from poseprobe_amd import utils, voxurf_coarse as Model
+    from poseprobe_amd.config import ConfigDict
+    from poseprobe_amd.engine import pack_rgbnet, pack_warp
+    from tests.test_hip_dropin import make_model
+    d = load('forward_g8_s10.npz')
+    m = make_model(d)
+    cfg_train = ConfigDict(lrate_decay=10, lrate_sdf_alpha=1e-2, lrate_sdf_beta=1e-2, lrate_k0=1e-1, lrate_rgbnet=1e-3,
+                           lrate_warp_network=1e-3)
+    opt = utils.create_optimizer_or_freeze_model(m, cfg_train, global_step=0)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(3):
+        for p in m.parameters():
+            if p.requires_grad and p.dim() > 0:
+                p.grad = (torch.randn(p.shape, generator=g) * 1e-3).to(p.device)
+        opt.step()
+    sd = opt.state_dict()
+    eng, _ = build_engine(d)
+    eng.load_optimizer_state_dict(sd)
+    assert eng.n_step == 3
+    st = lambda name, j: opt.state[[gr for gr in opt.param_groups if gr['name'] == name][0]['params'][j]]
+    n = lambda t: t.detach().cpu().numpy()
+    assert_close(n(eng.k0_m), n(st('k0', 0)['exp_avg'][0].permute(1, 2, 3, 0)), rtol=0, atol=0, name='k0 exp_avg')
+    assert_close(n(eng.k0_v), n(st('k0', 0)['exp_avg_sq'][0].permute(1, 2, 3, 0)), rtol=0, atol=0, name='k0 exp_avg_sq')
+    rg = [(st('rgbnet', 2 * i)['exp_avg'], st('rgbnet', 2 * i + 1)['exp_avg']) for i in range(4)]
+    assert_close(n(eng.flat.view('rgbnet', 'm')), n(pack_rgbnet(rg)), rtol=0, atol=0, name='rgbnet exp_avg (packed)')
+    wp = [(st('warp_network', 1 + 2 * i)['exp_avg_sq'], st('warp_network', 2 + 2 * i)['exp_avg_sq']) for i in range(5)]
+    assert_close(n(eng.flat.view('warp', 'v')), n(pack_warp(wp)), rtol=0, atol=0, name='warp exp_avg_sq (packed)')
+    assert_close(n(eng.flat.view('sdf_ab', 'm')), np.concatenate([n(st('sdf_alpha', 0)['exp_avg']), n(st('sdf_beta', 0)['exp_avg'])]),
+                 rtol=0, atol=0, name='alpha / beta exp_avg')
+    # and back: the engine's own export is accepted by the torch optimiser and equals what went in
+    back = eng.optimizer_state_dict()
+    opt2 = utils.create_optimizer_or_freeze_model(make_model(d), cfg_train, global_step=0)
+    opt2.load_state_dict(back)
+    for i, s_in in sd['state'].items():
+        assert torch.equal(back['state'][i]['exp_avg'].reshape(-1), s_in['exp_avg'].cpu().reshape(-1)), i
 
 
 def test_geometry_backward_with_fused_priors_is_bit_identical_to_the_two_kernel_route():
