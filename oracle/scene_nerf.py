@@ -37,8 +37,13 @@ def encode(x, L, w):
     return torch.cat([x, enc.flatten(-3)], dim=-1)
 
 
-def mlp(params, pts, ray, progress, barf_c2f):
-    """pts [R, S, 3], ray [R, 3] -> rgb_samples [R, S, 3], density [R, S]."""
+def mlp(params, pts, ray, progress, barf_c2f, masks=None, hidden=None):
+    """pts [R, S, 3], ray [R, 3] -> rgb_samples [R, S, 3], density [R, S].
+    Test instrumentation (never used by the fixtures): `hidden` (a list) collects the nine post-ReLU activations; `masks`
+    (nine boolean tensors) REPLACES every ReLU by a multiplication with the given 0 / 1 pattern, i.e. evaluates the network
+    on the linear piece another implementation chose - two fp32 implementations differ in the ReLU state of the few
+    pre-activations that lie within rounding distance of zero, and on a common piece their gradients agree tightly."""
+    act = (lambda x, i: F.relu(x)) if masks is None else (lambda x, i: x * masks[i].reshape(x.shape).to(x.dtype))
     e = encode(pts, L_3D, band_weights(progress, barf_c2f, L_3D, pts.dtype))
     h = e
     for li in range(N_FEAT_LAYERS):
@@ -47,12 +52,16 @@ def mlp(params, pts, ray, progress, barf_c2f):
         h = F.linear(h, params[f'mlp_feat.{li}.weight'], params[f'mlp_feat.{li}.bias'])
         if li == N_FEAT_LAYERS - 1:
             raw, h = h[..., 0], h[..., 1:]
-        h = F.relu(h)
+        h = act(h, li)
+        if hidden is not None:
+            hidden.append(h)
     density = F.softplus(raw)
     unit = ray / ray.norm(dim=-1, keepdim=True).clamp_min(1e-12)
     ve = encode(unit, L_VIEW, band_weights(progress, barf_c2f, L_VIEW, pts.dtype))
     h = torch.cat([h, ve[:, None, :].expand(*h.shape[:-1], ve.shape[-1])], -1)
-    h = F.relu(F.linear(h, params['mlp_rgb.0.weight'], params['mlp_rgb.0.bias']))
+    h = act(F.linear(h, params['mlp_rgb.0.weight'], params['mlp_rgb.0.bias']), N_FEAT_LAYERS)
+    if hidden is not None:
+        hidden.append(h)
     rgb = torch.sigmoid(F.linear(h, params['mlp_rgb.1.weight'], params['mlp_rgb.1.bias']))
     return rgb, density
 
@@ -73,10 +82,10 @@ def composite(rgb_s, density, depth, ray, white_bg=False):
     return out
 
 
-def render(params, center, ray, depth, progress, barf_c2f, white_bg=False):
+def render(params, center, ray, depth, progress, barf_c2f, white_bg=False, masks=None, hidden=None):
     """center, ray [R, 3]; depth [R, S]."""
     pts = center[:, None] + ray[:, None] * depth[..., None]
-    rgb_s, dens = mlp(params, pts, ray, progress, barf_c2f)
+    rgb_s, dens = mlp(params, pts, ray, progress, barf_c2f, masks, hidden)
     out = composite(rgb_s, dens, depth, ray, white_bg)
     out.update(rgb_samples=rgb_s, density_samples=dens)
     return out
