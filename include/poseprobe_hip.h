@@ -236,6 +236,11 @@ int pp_warp_bwd(const float* params, const float* pts, const float* acts, const 
                 float* params_grad /*atomic +=*/, float* pts_grad /* += */, void* ctx /*pp_context or NULL*/,
                 void* stream);
 
+/* Workspace queries (floats) for the `acts` and `scratch` arguments of the MLP entry points at a sample capacity. */
+int pp_rgbnet_workspace(int32_t capacity, int64_t* acts_floats, int64_t* scratch_floats);
+int pp_warp_workspace(int32_t capacity, int64_t* acts_floats, int64_t* scratch_floats);
+int pp_mlp_workspace(int32_t in_ld, int32_t n_gemm, int32_t capacity, int64_t* acts_floats, int64_t* scratch_floats);
+
 /* Two-stage forms of the two backward chains above (layer-fused kernels only; option mlp_fused = 0 returns
  * PP_ERR_UNSUPPORTED): stage 1 = data gradients + thin-layer and bias gradients, leaves the hidden layers' output gradients
  * in `scratch`; stage 2 = the hidden layers' weight gradients from `scratch` and the stored activations.

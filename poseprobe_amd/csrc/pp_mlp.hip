@@ -574,3 +574,29 @@ extern "C" int pp_rgbnet_bwd_weights(const float* feat, const float* acts, const
   PP_CHECK_LAUNCH();
   return PP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Workspace queries: floats the caller must provide for `acts` (kept from forward to backward) and `scratch` (backward
+// only) of the MLP entry points at a given sample capacity.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int pp_rgbnet_workspace(int32_t capacity, int64_t* acts_floats, int64_t* scratch_floats) {
+  PP_REQUIRE(acts_floats && scratch_floats && capacity > 0, "bad arguments");
+  *acts_floats = (int64_t)3 * capacity * 128;
+  *scratch_floats = (int64_t)3 * capacity * 128 + 49152;          // Ybar of the three hidden layers (+ transposed weights, layered path)
+  return PP_OK;
+}
+
+extern "C" int pp_warp_workspace(int32_t capacity, int64_t* acts_floats, int64_t* scratch_floats) {
+  PP_REQUIRE(acts_floats && scratch_floats && capacity > 0, "bad arguments");
+  *acts_floats = (int64_t)4 * capacity * 4 * 128;                 // four hidden activations of the 4-row form
+  *scratch_floats = (int64_t)3 * capacity * 4 * 128 + 49152;
+  return PP_OK;
+}
+
+extern "C" int pp_mlp_workspace(int32_t in_ld, int32_t n_gemm, int32_t capacity, int64_t* acts_floats, int64_t* scratch_floats) {
+  PP_REQUIRE(acts_floats && scratch_floats && capacity > 0 && in_ld % 32 == 0 && in_ld <= 128 && n_gemm >= 1 && n_gemm <= 8,
+             "bad arguments");
+  *acts_floats = (int64_t)n_gemm * capacity * 128;
+  *scratch_floats = (int64_t)(n_gemm > 3 ? n_gemm : 3) * capacity * 128 + 49152;
+  return PP_OK;
+}

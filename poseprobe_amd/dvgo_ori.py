@@ -9,6 +9,7 @@ detached.
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops, render_utils
 from .engine import SceneConfig
@@ -291,3 +292,73 @@ class DirectVoxGO(torch.nn.Module):
 
     def extract_geometry(self, *a, **k):
         raise NotImplementedError('mesh extraction needs `mcubes`, which is out of scope of the hot path (DESIGN.md 8)')
+
+
+# ---- remaining names of lib/dvgo_ori.py's module surface ---------------------------------------------------------
+class MaskCache(torch.nn.Module):
+    """lib/dvgo_ori.py:440-473: occupancy query alpha(xyz) >= threshold on the max-pooled density grid of a coarse-stage
+    checkpoint.  The checkpoint is read weights-only (utils.load_checkpoint_file); the lookup is the HIP trilinear operator
+    of DenseGrid (align_corners, zeros padding), the activation is the reference's post-activation form (`nearest`,
+    `pre_act_density`, `in_act_density` select the reference's other three forms)."""
+
+    def __init__(self, path, mask_cache_thres, ks=3):
+        super().__init__()
+        from .grid import DenseGrid
+        from .utils import load_checkpoint_file
+        st = load_checkpoint_file(path)
+        kw = st['MaskCache_kwargs']
+        self.mask_cache_thres = mask_cache_thres
+        density = F.max_pool3d(torch.as_tensor(st['model_state_dict']['density'], dtype=torch.float32), kernel_size=ks,
+                               padding=ks // 2, stride=1)
+        self.act_shift, self.voxel_size_ratio = float(kw['act_shift']), float(kw['voxel_size_ratio'])
+        self.nearest = bool(kw.get('nearest', False))
+        self.pre_act_density, self.in_act_density = bool(kw.get('pre_act_density', False)), bool(kw.get('in_act_density', False))
+        if self.nearest:
+            raise NotImplementedError('MaskCache(nearest=True): no shipped configuration uses nearest-neighbour lookups')
+        if self.pre_act_density:                             # (the reference then samples the RAW density: lib/dvgo_ori.py:463-465)
+            pass
+        elif self.in_act_density:
+            density = F.softplus(density + self.act_shift)
+        self.grid = DenseGrid(channels=1, world_size=list(density.shape[2:]), xyz_min=np.asarray(kw['xyz_min'], np.float32),
+                              xyz_max=np.asarray(kw['xyz_max'], np.float32))
+        self.grid.grid.data = density.contiguous(memory_format=torch.channels_last_3d)
+        self.grid.grid.requires_grad = False
+        self.register_buffer('xyz_min', self.grid.xyz_min.clone())
+        self.register_buffer('xyz_max', self.grid.xyz_max.clone())
+
+    @property
+    def density(self):
+        return self.grid.grid
+
+    @torch.no_grad()
+    def forward(self, xyz):
+        val = self.grid(xyz.reshape(-1, 3)).reshape(xyz.shape[:-1])
+        if self.pre_act_density:
+            alpha = val
+        elif self.in_act_density:
+            alpha = 1 - torch.exp(-val * self.voxel_size_ratio)
+        else:
+            alpha = 1 - torch.exp(-F.softplus(val + self.act_shift) * self.voxel_size_ratio)
+        return alpha >= self.mask_cache_thres
+
+
+def extract_fields(bound_min, bound_max, resolution, query_func, N=64):
+    """lib/dvgo_ori.py:679-693: query_func sampled on a resolution^3 lattice of the box, in blocks of N^3 points."""
+    axes = [torch.linspace(float(bound_min[a]), float(bound_max[a]), resolution) for a in range(3)]
+    u = np.zeros([resolution] * 3, dtype=np.float32)
+    with torch.no_grad():
+        for x0 in range(0, resolution, N):
+            for y0 in range(0, resolution, N):
+                for z0 in range(0, resolution, N):
+                    xs, ys, zs = axes[0][x0:x0 + N], axes[1][y0:y0 + N], axes[2][z0:z0 + N]
+                    pts = torch.stack(torch.meshgrid(xs, ys, zs, indexing='ij'), dim=-1).reshape(-1, 3)
+                    val = query_func(pts).reshape(len(xs), len(ys), len(zs))
+                    u[x0:x0 + len(xs), y0:y0 + len(ys), z0:z0 + len(zs)] = val.detach().cpu().numpy()
+    return u
+
+
+def extract_geometry(bound_min, bound_max, resolution, threshold, query_func, N=64):
+    """lib/dvgo_ori.py:695-703 needs `mcubes.marching_cubes`, which is not available offline: the sampled field is what
+    this package can deliver (extract_fields); triangulate it with any marching-cubes implementation."""
+    raise NotImplementedError('extract_geometry (lib/dvgo_ori.py:695-703): marching cubes (`mcubes`) is not available '
+                              'offline; use extract_fields(...) and triangulate the returned lattice elsewhere')

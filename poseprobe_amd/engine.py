@@ -91,6 +91,8 @@ class Workspace:
         self.count = torch.zeros(1, **i)
         # samples
         self.pts, self.ray_id, self.step_k, self.step = e(sc_, 3, **f), e(sc_, **i), e(sc_, **i), e(sc_, **f)
+        wsz = ops.mlp_workspaces(capacity)                 # sizes come from the library (pp_rgbnet_workspace / pp_warp_workspace)
+        assert wsz['warp'][0] == 4 * capacity * 4 * 128 and wsz['rgbnet'][0] == 3 * capacity * 128
         self.warp_acts = e(4, capacity * 4, 128, **f)
         self.warp_out = e(capacity, 16, **f)
         self.alpha, self.gradient = e(capacity, **f), e(capacity, 3, **f)
@@ -114,8 +116,8 @@ class Workspace:
         self.g_gradient, self.g_pts, self.g_view_s = e(capacity, 3, **f), e(capacity, 3, **f), e(capacity, 3, **f)
         self.g_grad_deform, self.g_corr, self.g_sdf_deform = e(capacity, 9, **f), e(capacity, **f), e(capacity, **f)
         self.g_warp_out = e(capacity, 16, **f)
-        self.scratch = e(3 * capacity * 4 * 128 + 49152, **f)   # Ybar of the warp chain (+ transposed weights, layered path)
-        self.scratch_rgb = e(3 * capacity * 128 + 49152, **f)   # Ybar of rgbnet: its weight-gradient kernel may still be
+        self.scratch = e(wsz['warp'][1], **f)              # Ybar of the warp chain (+ transposed weights, layered path)
+        self.scratch_rgb = e(wsz['rgbnet'][1], **f)   # Ybar of rgbnet: its weight-gradient kernel may still be
         #                                                         reading it on the side stream while the warp chain runs
         self.g_rays_o, self.g_rays_d, self.g_viewdirs = e(N, 3, **f), e(N, 3, **f), e(N, 3, **f)
 

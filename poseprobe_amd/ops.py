@@ -220,6 +220,16 @@ def warp_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, p
               _f(scratch), _f(params_grad), _f(pts_grad), ctx, _stream())
 
 
+def mlp_workspaces(capacity):
+    """-> {'rgbnet': (acts, scratch), 'warp': (acts, scratch)} in floats, from the library's workspace queries."""
+    out = {}
+    for name in ('rgbnet', 'warp'):
+        a, s = ctypes.c_int64(), ctypes.c_int64()
+        _lib.call(f'pp_{name}_workspace', int(capacity), ctypes.byref(a), ctypes.byref(s))
+        out[name] = (a.value, s.value)
+    return out
+
+
 def warp_bwd_data(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad):
     _lib.call('pp_warp_bwd_data', _f(params), _f(pts), _f(acts), _f(out_grad), _i(count), capacity, float(out_range),
               _f(scratch), _f(params_grad), _f(pts_grad), _stream())

@@ -713,3 +713,120 @@ def get_training_rays(rgb_tr, mask_tr, train_poses, HW, Ks, ndc, inverse_y, flip
     outs = [get_rays_of_a_view(int(H), int(W), K, c2w, ndc, inverse_y, flip_x, flip_y) for c2w in train_poses]
     return (rgb_tr, mask_tr, torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]),
             torch.stack([o[2] for o in outs]), [1] * len(rgb_tr))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Remaining names of the reference's module surface.  None of the shipped end-to-end configurations reaches
+# them (`ray_sampler='flatten'`, no mask cache), but a caller that imports `lib.voxurf_coarse as Model` finds them here, on
+# the same HIP operators as the live path.
+# ----------------------------------------------------------------------------------------------------------------------
+class MaskCache(nn.Module):
+    """Known-free-space query of a coarse SDF (lib/voxurf_coarse.py:1271-1296): forward(xyz) = sdf(xyz) < threshold with the
+    trilinear lookup of DenseGrid (align_corners, zeros padding).  `path`: an .npz with `sdf_grid_xyz [X,Y,Z]`, `xyz_min`,
+    `xyz_max` (weights-only load).  The reference reads a pickled dict from an .npy; such a file is refused rather than
+    unpickled - convert it once with numpy on the side that trusts it."""
+
+    def __init__(self, path, mask_cache_thres, ks=3):
+        super().__init__()
+        try:
+            d = np.load(path, allow_pickle=False)
+            sdf0, lo, hi = d['sdf_grid_xyz'], d['xyz_min'], d['xyz_max']
+        except (ValueError, KeyError, IndexError, TypeError) as e:
+            raise ValueError(f'MaskCache: {path} is not an .npz with sdf_grid_xyz / xyz_min / xyz_max (a pickled dict, as '
+                             'lib/voxurf_coarse.py:1274 reads, is not loaded: it could execute code)') from e
+        self.mask_cache_thres = mask_cache_thres
+        self.nearest = False
+        self.grid = grid.DenseGrid(channels=1, world_size=list(sdf0.shape), xyz_min=np.asarray(lo, np.float32),
+                                   xyz_max=np.asarray(hi, np.float32))
+        self.grid.grid.data = torch.tensor(np.asarray(sdf0, np.float32))[None, None].contiguous(memory_format=torch.channels_last_3d)
+        self.grid.grid.requires_grad = False
+        self.register_buffer('xyz_min', self.grid.xyz_min.clone())
+        self.register_buffer('xyz_max', self.grid.xyz_max.clone())
+
+    @property
+    def sdf(self):
+        return self.grid.grid
+
+    @torch.no_grad()
+    def forward(self, xyz):
+        return self.grid(xyz.reshape(-1, 3)).reshape(xyz.shape[:-1]) < self.mask_cache_thres
+
+
+def get_rays_of_a_view_semantic(H, W, K, c2w, ndc, inverse_y, flip_x, flip_y, background_sampler, object_sampler,
+                                boundary_sampler, mode='center'):
+    """lib/voxurf_coarse.py:1410-1453: rays at pixels drawn 20 % / 30 % / 50 % from the background / boundary / object
+    pixel lists (each sampler = (ys, xs)); returns rays_o, rays_d, viewdirs and [x, y] of the drawn pixels.  Like the
+    reference's variant (and unlike get_rays_of_a_view) rays_d stays un-normalised."""
+    if ndc or flip_x or flip_y or mode != 'center':
+        raise NotImplementedError('semantic sampler: only mode="center" without flips / NDC (the reference\'s flips index a '
+                                  '1-D tensor along dimension 1 and would fail as well)')
+    n = min(boundary_sampler[0].shape[0], object_sampler[0].shape[0])
+    parts = []
+    for sampler, share in ((background_sampler, 0.2), (boundary_sampler, 0.3), (object_sampler, 0.5)):
+        pick = torch.randint(low=0, high=sampler[0].shape[0], size=[int(n * share)])
+        parts.append((sampler[0][pick], sampler[1][pick]))
+    y = torch.cat([p[0] for p in parts]).long()
+    x = torch.cat([p[1] for p in parts]).long()
+    dev = c2w.device
+    idx = (y * W + x).to(dev).int().contiguous()
+    o, d, v = _RaysAtPixels.apply(c2w[None, :3, :4], idx, _intr_of(K, dev), H, W, bool(inverse_y), False)
+    return o, d, v, [x, y]
+
+
+def get_training_rays_semantic(rgb_tr_ori, mask_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y, samplers):
+    """lib/voxurf_coarse.py:1456-1491."""
+    rgb, msk, ro, rd, vd, imsz = [], [], [], [], [], []
+    for i, (c2w, img, mask, (H, W), K) in enumerate(zip(train_poses, rgb_tr_ori, mask_tr_ori, HW, Ks)):
+        o, d, v, (x, y) = get_rays_of_a_view_semantic(int(H), int(W), K, c2w, ndc, inverse_y, flip_x, flip_y,
+                                                     samplers['background'][i], samplers['object'][i], samplers['boundary'][i])
+        x, y = x.to(img.device), y.to(img.device)
+        rgb.append(img[y, x]), msk.append(mask[y, x]), ro.append(o), rd.append(d), vd.append(v), imsz.append(o.shape[0])
+    return torch.cat(rgb), torch.cat(msk), torch.cat(ro), torch.cat(rd), torch.cat(vd), imsz
+
+
+def get_training_rays_in_maskcache_sampling_grad(rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y, model,
+                                                 render_kwargs):
+    """lib/voxurf_coarse.py:1552-1588: the rays of every view that have at least one sample inside the bounding box AND in
+    the mask cache's known space; differentiable w.r.t. the poses (the selection itself is not)."""
+    assert len(rgb_tr_ori) == len(train_poses) and len(rgb_tr_ori) == len(Ks) and len(rgb_tr_ori) == len(HW)
+    if getattr(model, 'mask_cache', None) is None:
+        raise ValueError('in_maskcache sampling needs model.mask_cache (a MaskCache)')
+    rgb, ro, rd, vd, imsz = [], [], [], [], []
+    CHUNK = 4096
+    for c2w, img, (H, W), K in zip(train_poses, rgb_tr_ori, HW, Ks):
+        H, W = int(H), int(W)
+        assert img.shape[:2] == (H, W)
+        o, d, v = get_rays_of_a_view(H, W, K, c2w, ndc, inverse_y, flip_x, flip_y)
+        o, d, v = o.reshape(-1, 3), d.reshape(-1, 3), v.reshape(-1, 3)
+        hit = torch.zeros(H * W, dtype=torch.bool, device=o.device)
+        with torch.no_grad():
+            for b in range(0, H * W, CHUNK):
+                pts, out, _, _, _ = model.sample_ray_ori(rays_o=o[b:b + CHUNK].detach(), rays_d=d[b:b + CHUNK].detach(),
+                                                         **render_kwargs)
+                inside = ~out
+                inside[inside.clone()] &= model.mask_cache(pts[inside])
+                hit[b:b + CHUNK] = inside.any(-1)
+        rgb.append(img.reshape(-1, img.shape[-1])[hit.to(img.device)]), ro.append(o[hit]), rd.append(d[hit]), vd.append(v[hit])
+        imsz.append(int(hit.sum()))
+    return torch.cat(rgb), torch.cat(ro), torch.cat(rd), torch.cat(vd), imsz
+
+
+@torch.no_grad()
+def get_training_rays_in_maskcache_sampling(rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y, model,
+                                            render_kwargs):
+    """lib/voxurf_coarse.py:1591-1631 (the no-grad twin of the function above)."""
+    return get_training_rays_in_maskcache_sampling_grad(rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y, model,
+                                                        render_kwargs)
+
+
+def _no_mesh(name, where):
+    def method(self, *a, **k):
+        raise NotImplementedError(f'{name} ({where}): marching cubes (`mcubes`) is not available offline and mesh '
+                                  'extraction is outside the hot path (DESIGN.md 8); query the SDF with '
+                                  'Voxurf.query_sdf_point_wocuda* or sample `sdf.grid` directly')
+    method.__name__ = name
+    return method
+
+
+Voxurf.extract_deform_geometry = _no_mesh('extract_deform_geometry', 'lib/voxurf_coarse.py:1224-1248')
+Voxurf.extract_geometry = _no_mesh('extract_geometry', 'lib/voxurf_coarse.py:1250-1263')
