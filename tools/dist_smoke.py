@@ -74,7 +74,8 @@ def worker(rank, world, port, mode, q):
     outs = [None] * world
     dist.all_gather_object(outs, (k0, flat, se3))
     if rank == 0:
-        q.put((outs, g))
+        # numpy: pickled by value (torch tensors travel as file descriptors that die with this process)
+        q.put(([[t.numpy() for t in o] for o in outs], [t.numpy() for t in g]))
     dist.destroy_process_group()
 
 
@@ -87,7 +88,8 @@ if __name__ == '__main__':
     for p in procs: p.start()
     outs, g_sharded = q.get(timeout=240)
     for p in procs: p.join(60)
-    (k0a, fa, sa), (k0b, fb, sb) = outs
+    (k0a, fa, sa), (k0b, fb, sb) = [[torch.from_numpy(t) for t in o] for o in outs]
+    g_sharded = [torch.from_numpy(t) for t in g_sharded]
     print(f'[{mode}] replicas: max|k0 diff| {float((k0a - k0b).abs().max()):.3e}  max|mlp diff| {float((fa - fb).abs().max()):.3e}  '
           f'max|se3 diff| {float((sa - sb).abs().max()):.3e}')
     # single process over the union of the rays (global batch 2 x 256).  The sharded step normalises its losses over the union
