@@ -17,6 +17,7 @@ Prints ONE JSON line on rank 0 (driver contract).  Objects besides the contract'
   dual_branch       BASELINE config 2 as the reference runs it: object step + scene branch (bg_nerf) sharing the poses;
                     its rays/s and ms/step are repeated as top-level fields `dual_branch_rays_per_s`, `dual_branch_ms_per_step`
   roofline_scene    the scene branch's forward + backward GEMM chains against the fp16 MFMA pipe they issue on
+  inference         whole-view inference as the reference evaluates (lib/nvs_fun.py: 4096-ray chunks of Voxurf.inference): rays/s
   cpu_baseline      the oracle (CPU restatement, "port") timed on this host's cores for a bounded sample (N=1, rank 0)
   psnr_parity       oracle and HIP engine trained from one initialisation with the same per-step rays and jitter; PSNR of
                     both on held-out pixels and their difference (BASELINE metric: "PSNR parity", <= 0.1 dB)
@@ -376,6 +377,38 @@ def dual_branch_leg(eng, idx_all, jit_all, gs, N, V, H, W, object_ms, dev, steps
     return out
 
 
+def inference_leg(dev, G, H, W, reps=3):
+    """Whole-view inference the way the reference evaluates (lib/nvs_fun.py:39-86: every pixel of a view through
+    Voxurf.inference in 4096-ray chunks): rays/s for one H x W view at the bench grid, drop-in module path."""
+    import numpy as np
+    import torch
+    from poseprobe_amd import nvs_fun, synthetic as syn
+    from poseprobe_amd import voxurf_coarse as Model
+    rs = syn.range_shape()
+    m = Model.Voxurf(syn.XYZ_MIN, syn.XYZ_MAX, num_voxels=G ** 3, num_voxels_base=G ** 3, alpha_init=1e-2, rgbnet_dim=12,
+                     rgbnet_direct=True, rgbnet_depth=4, rgbnet_width=128, posbase_pe=5, viewbase_pe=1, geo_rgb_dim=3,
+                     s_ratio=50, s_start=0.2, barf_c2f=[0.6, 1], i_train=np.arange(3), N_iters=10000,
+                     HW=np.array([[H, W]] * 3), range_shape=rs, rect_size=rs.tolist(), camera_noise=0.).to(dev)
+    with torch.no_grad():
+        m.k0.grid.normal_(0, 0.1)
+    K = torch.tensor(syn.intrinsics(1, H, W)[0], device=dev)
+    c2w = torch.eye(4)
+    c2w[:3] = torch.tensor(syn.cameras(3)[1])
+    c2w = torch.linalg.inv(c2w)[:3].to(dev)
+    kw = dict(near=syn.NEAR, far=syn.FAR, bg=0, stepsize=1.5, inverse_y=True)
+    nvs_fun.render_view(m, H, W, K, c2w, False, kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        nvs_fun.render_view(m, H, W, K, c2w, False, kw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    del m
+    torch.cuda.empty_cache()
+    return {'rays_per_s': H * W / dt, 'ms_per_view': dt * 1e3, 'workload': f'one {H}x{W} view, {G}^3 grid, Voxurf.inference in '
+            f'{nvs_fun.CHUNK}-ray chunks (rgb, disparity, opacity, normals), images assembled on the device'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -585,6 +618,7 @@ def main():
             out['dual_branch_ms_per_step'] = dual['coarse_phase']['ms_per_step']
             out['dual_branch_hierarchical_rays_per_s'] = dual['hierarchical_phase']['rays_per_s']
             out['roofline_scene'] = dual.pop('roofline_scene', None)
+        out['inference'] = inference_leg(dev, G, H, W) if world == 1 else None
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(G, H, W, V, N, views, args.cpu_budget)
         else:

@@ -17,6 +17,9 @@ OBJ = os.path.join(CSRC, '_obj')
 OUT = os.path.join(HERE, 'libposeprobe_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-Wno-pass-failed', '-Wno-unused-result',
          '-Wno-unused-value']
+# per-source flags.  pp_mlp_split.hip: the SLP vectoriser turns the epilogue arithmetic into v_pk_*_f32, which on gfx950 does not
+# overlap with MFMAs (tools/mfma_valu_probe.hip: two v_pk_fma_f32 between MFMAs double the loop time, four plain VALU are free)
+SOURCE_FLAGS = {'pp_mlp_split.hip': ['-fno-slp-vectorize']}
 
 
 def sources():
@@ -58,7 +61,7 @@ def build(force=False, verbose=True):
     todo = sources() if force else stale_sources()
 
     def compile_one(src):
-        cmd = [hipcc] + FLAGS + extra + ['-c', src, '-o', _obj(src)]
+        cmd = [hipcc] + FLAGS + SOURCE_FLAGS.get(os.path.basename(src), []) + extra + ['-c', src, '-o', _obj(src)]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

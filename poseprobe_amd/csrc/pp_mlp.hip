@@ -449,7 +449,8 @@ extern "C" int pp_warp_fwd(const float* params, const float* pts, const int32_t*
   PP_REQUIRE(capacity > 0, "capacity<=0");
   hipStream_t st = pp_stream(stream);
   if (mlp_fused_enabled()) {
-    pp_launch_warp_fused_fwd(params, pts, count, capacity, out_range, acts, out, st);
+    if (pp_opt(PP_OPT_MLP_SPLIT) & 1) pp_launch_warp_fused_fwd_s(params, pts, count, capacity, out_range, acts, out, st);
+    else pp_launch_warp_fused_fwd(params, pts, count, capacity, out_range, acts, out, st);
     PP_CHECK_LAUNCH();
     return PP_OK;
   }

@@ -1,0 +1,494 @@
+// Layer-fused object-branch MLP kernels, split-precision variant (option "mlp_split"): the structure of pp_mlp_fused.hip
+// - one persistent work-group per CU walks a 64-row tile through all layers, hidden-layer weights stationary in registers,
+// activations in LDS between the layers - with every 128 x 128 product evaluated as THREE fp16 products
+// lo.hi + hi.lo + hi.hi on v_mfma_f32_32x32x16_f16 (fp32 accumulation) instead of v_mfma_f32_32x32x2_f32:
+// 3 x 32 matrix-pipe cycles per 32 x 32 x 16 block instead of 8 x 64.  Operands and results in memory stay fp32; the error
+// against an fp64 product equals the fp32 instructions' (pp_gemm_split.h, tools/split_gemm_probe.hip).
+//
+// Scales.  x * s = hi + lo needs a power of two s with max|x| * s < 2^16.  Weights: s from max|W| of the layer, found once
+// per work-group in the prologue.  Activations live only inside the kernel, one tile at a time, so their scale is PER TILE AND
+// LAYER and must be known when the producing epilogue converts - before the tile's maximum exists.  It comes from a bound
+// instead: |y[r][n]| <= max|x| * max_n sum_k |W[n][k]| + max|b|, with max|x| the EXACT maximum of the previous layer's tile
+// (every lane folds what it writes into an LDS slot by ds_max_u32 on the float bits; the barrier that publishes the tile
+// publishes the slot).  The bound is loose by 2^3..2^6, which costs nothing: hi / lo carry 22 significant bits down to
+// 2^-18 of the largest representable value and an absolute floor of 2^-40 of it below that.
+//
+// LDS image of a tile: hi plane [64][136] halfs, lo plane [64][136] halfs (272-byte rows: the 16 rows of a ds_read_b128
+// lane group start 4 banks apart and cover all 64 banks once; the epilogue's 2-byte stores of 32 consecutive features are
+// conflict-free).
+//
+// Orientation.  The fp32 kernels compute D = X . W^T with the activations as the MFMA A operand, so a lane ends up with 16
+// ROWS of one feature: one scalar LDS / HBM store per element, ~17 instructions per element in the epilogue - with the matrix
+// time cut to a fifth that is what the kernel then waits for.  Here the roles are swapped: A = weights (feature l31 of the
+// wavefront's 32, k = 16 ks + 8 lh + j; register content as before), B = activations (row l31), D[reg][lane] = out[row l31]
+// [feature 32 w + (reg & 3) + 8 (reg >> 2) + 4 lh]: a lane holds four runs of four CONSECUTIVE features of one row, so the
+// epilogue works on packed pairs (v_pk_fma_f32, v_cvt_pk_f16_f32) and stores 8 bytes per LDS write and 16 bytes per HBM
+// write.  The four rows of a warp sample are the four lanes of a quad; the primal row's ReLU state reaches the tangent rows
+// by a quad-broadcast DPP operand.  The input layer (3 -> 128 on [p, 1] / unit tangents) is one more MFMA with K padded to 16.
+//
+// Schedule.  With the matrix time cut to a fifth the epilogues (scale, gate, split, store: ~8 instructions per element) cost
+// more than the MFMAs; a lone wavefront per SIMD can only hide them if they are ISSUED between MFMAs.  A tile is therefore
+// processed as two 32-row halves, each with its own accumulators, scale and maximum slot, in a software pipeline
+//   A_l: MFMAs of (layer l, half 0)  interleaved with the epilogue of (layer l-1, half 1)
+//   B_l: MFMAs of (layer l, half 1)  interleaved with the epilogue of (layer l,   half 0)
+// with one LDS-only barrier after each stage (the rows a stage's MFMAs read were published by the barrier before it).
+#include "pp_common.h"
+#include "pp_mlp_fused.h"
+#include "pp_gemm_split.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LDA 132                 // fp32 view of a tile (output layer input), as in pp_mlp_fused.hip
+#define TILE_ROWS 64
+#define LDH2 136                // halfs per row of a split tile
+#define PLANE (TILE_ROWS * LDH2)
+#ifndef MS_DBG
+#define MS_DBG 0      // experiments only: 1 = no MFMAs, 2 = no HBM activation stores, 3 = no LDS writes in the epilogues, 4 = no conversions
+#endif
+#ifdef MS_TIMERS      // phase timers (experiments): wave 0 of every work-group sums s_memtime deltas per phase
+__device__ unsigned long long g_ms_t[16];
+extern "C" int pp_debug_read_timers(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ms_t), sizeof(g_ms_t)) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ms_t), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#define TICK(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); tsum[i] += t__ - tprev; tprev = t__; } while (0)
+#else
+#define TICK(i) do {} while (0)
+#endif
+#define PP_WAIT_VMEM() do { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while (0)
+
+namespace {
+
+struct SplitW { pp_half8 h[8], l[8]; };      // one layer's share of a lane: 64 registers, as the fp32 layout
+
+template <bool B> struct BoolC { static constexpr bool value = B; };
+#define PP_WITH_FULL(cond, f) do { if (cond) f(BoolC<true>{}); else f(BoolC<false>{}); } while (0)
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide maximum of a non-negative value (prologue only)
+__device__ __forceinline__ float block_max(float v, float* red, int tid) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+// exponent e of the power of two with mx * 2^e in [2^14, 2^15), clamped to +-60 so that products of two scales stay finite;
+// scales are kept as exponents: reciprocals and products are integer arithmetic + one v_ldexp_f32
+__device__ __forceinline__ int scale_exp(float mx) {
+  if (!(mx > 0.f) || !(mx < 3.0e38f)) return 0;
+  int e;
+  frexpf(mx, &e);
+  return min(max(15 - e, -60), 60);
+}
+__device__ __forceinline__ float pow2(int e) { return ldexpf(1.f, e); }
+__device__ __forceinline__ float tile_scale(float mx) { return pow2(scale_exp(mx)); }
+__device__ __forceinline__ void split1(float x, _Float16& h, _Float16& l) {
+  h = (_Float16)x;
+  l = (_Float16)(x - (float)h);
+}
+__device__ __forceinline__ void split8(const float4& a, const float4& b, float s, pp_half8& h, pp_half8& l) {
+  const float v[8] = {a.x * s, a.y * s, a.z * s, a.w * s, b.x * s, b.y * s, b.z * s, b.w * s};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    _Float16 hh, ll;
+    split1(v[i], hh, ll);
+    h[i] = hh; l[i] = ll;
+  }
+}
+__device__ __forceinline__ float amax4(const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+__device__ __forceinline__ float asum4(const float4& v) { return (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w)); }
+
+// forward weights of feature n: k = 16 ks + 8 lh + j.  Returns the exponent of the layer's scale; l1 = max_n sum_k |W[n][k]|.
+__device__ __forceinline__ int load_w_rows_split(SplitW& w, float& l1, const float* __restrict__ W, int n, int lh, float* red,
+                                                   int tid) {
+  float4 v[16];
+  float mx = 0.f, sum = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    v[2 * ks] = *reinterpret_cast<const float4*>(W + (size_t)n * 128 + 16 * ks + 8 * lh);
+    v[2 * ks + 1] = *reinterpret_cast<const float4*>(W + (size_t)n * 128 + 16 * ks + 8 * lh + 4);
+    mx = fmaxf(mx, fmaxf(amax4(v[2 * ks]), amax4(v[2 * ks + 1])));
+    sum += asum4(v[2 * ks]) + asum4(v[2 * ks + 1]);
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  const int e = scale_exp(block_max(mx, red, tid));
+  const float s = pow2(e);
+  l1 = block_max(sum, red, tid) * 1.0001f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) split8(v[2 * ks], v[2 * ks + 1], s, w.h[ks], w.l[ks]);
+  return e;
+}
+
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+// acc[reg] += sum_k W[feature(reg)][k] X[row l31][k]  for 32 rows of a split tile (`rows` = hi plane of the first of them, lo
+// plane PLANE halfs behind); hook(ks), ks = 0..7, is called after the three MFMAs of every operand group - work placed there is
+// issued in the shadow of the matrix pipe
+template <class Hook = NoHook>
+__device__ __forceinline__ void mma_half(const _Float16* __restrict__ rows, const SplitW& w, f32x16& acc, int l31, int lh,
+                                         Hook hook = Hook()) {
+  const _Float16* p = rows + l31 * LDH2 + 8 * lh;
+  pp_half8 h = *reinterpret_cast<const pp_half8*>(p), l = *reinterpret_cast<const pp_half8*>(p + PLANE);
+#pragma unroll
+  for (int ks = 0; ks < (MS_DBG == 1 ? 0 : 8); ++ks) {
+    pp_half8 nh = h, nl = l;
+    if (ks + 1 < 8) {
+      nh = *reinterpret_cast<const pp_half8*>(p + 16 * (ks + 1));
+      nl = *reinterpret_cast<const pp_half8*>(p + 16 * (ks + 1) + PLANE);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h[ks], l, acc, 0, 0, 0);      // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.l[ks], h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h[ks], h, acc, 0, 0, 0);
+    h = nh; l = nl;
+    hook(ks);
+  }
+}
+
+__device__ __forceinline__ void zero16(f32x16& acc) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+}
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+// Epilogue of one 32-row half, lane = row, registers = features fb + 8 q + c, as EIGHT batched steps so that it can be issued
+// between the MFMAs of another half (step i after operand group i).  y = acc * inv + bias; COLS == 4: `bias` is zero in the
+// tangent lanes and the sign of the primal lane's pre-activation gates the whole quad (y == +0 counts as open: rows that are
+// exactly zero have zero tangents as well); fp32 copy to HBM for the backward pass (rows with `ok`), next tile to LDS as a split
+// image scaled by snext (SPLIT) or as the fp32 view.
+// Every step is a batch over all 16 elements with no instruction depending on its predecessor: a lone wavefront per SIMD has
+// nothing else to issue while a VALU result matures (DPP needs two wait states after the write of its source, v_cndmask one
+// after v_cmp writes VCC - hence sign-bit arithmetic instead of compares), and the scheduler is fenced between steps so that it
+// cannot re-serialise them.
+template <int COLS, bool SPLIT>
+struct HalfEpilogue {
+  float4 b[4];
+  float y[16];              // y -> gated value v
+  float p[16];              // primal pre-activation of the quad -> scaled value x
+  unsigned h[8], l[8];
+  float xmax;
+  // brow: this lane's bias row in LDS + fb (the real biases in primal lanes, a row of zeros in tangent lanes when COLS == 4)
+  __device__ __forceinline__ void begin(const float* __restrict__ brow) {
+    xmax = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const float4*>(brow + 8 * q);
+  }
+  __device__ __forceinline__ void step(int i, const f32x16& acc, float inv, float snext, bool ok, float* __restrict__ Crow,
+                                       _Float16* __restrict__ Arow) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (i == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        y[4 * q] = fmaf(acc[4 * q], inv, b[q].x); y[4 * q + 1] = fmaf(acc[4 * q + 1], inv, b[q].y);
+        y[4 * q + 2] = fmaf(acc[4 * q + 2], inv, b[q].z); y[4 * q + 3] = fmaf(acc[4 * q + 3], inv, b[q].w);
+      }
+    } else if (i == 1) {
+      // (inline assembly from here on: the compiler rewrites the sign-bit arithmetic into v_cmp / v_cndmask pairs through VCC)
+      if (COLS == 4) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          asm("v_mov_b32_dpp %0, %1 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(p[e]) : "v"(y[e]));
+#pragma unroll
+        for (int e = 0; e < 16; ++e) asm("v_ashrrev_i32 %0, 31, %1" : "=v"(p[e]) : "v"(p[e]));      // all ones where the primal row is negative
+      }
+    } else if (i == 2) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (COLS == 4) asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(y[e]) : "v"(p[e]), "v"(y[e]));          // y & ~mask
+        else y[e] = fmaxf(y[e], 0.f);
+      }
+    } else if (i == 3) {
+      if (ok && MS_DBG != 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(Crow + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+      }
+      if (!SPLIT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(Arow) + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+      }
+    } else if (SPLIT && i == 4) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) p[e] = y[e] * snext;
+    } else if (SPLIT && i == 5) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h[k]) : "v"(p[2 * k]), "v"(p[2 * k + 1]));
+        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(xmax) : "v"(p[2 * k]), "v"(p[2 * k + 1]));
+      }
+    } else if (SPLIT && i == 6) {
+      // lo = x - hi: fp32 fma on the f16 hi half, rounded once into the packed result
+#pragma unroll
+      for (int k = 0; k < 8; ++k) asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l[k]) : "v"(h[k]), "v"(p[2 * k]));
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[k]) : "v"(h[k]), "v"(p[2 * k + 1]));
+    } else if (SPLIT && i == 7 && MS_DBG != 3) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<uint2*>(Arow + 8 * q) = make_uint2(h[2 * q], h[2 * q + 1]);
+        *reinterpret_cast<uint2*>(Arow + 8 * q + PLANE) = make_uint2(l[2 * q], l[2 * q + 1]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void all(const f32x16& acc, float inv, float snext, bool ok, float* __restrict__ Crow, _Float16* __restrict__ Arow) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) step(i, acc, inv, snext, ok, Crow, Arow);
+  }
+  // max |v| of what this lane wrote (xmax holds it in scaled units; ninv = 1 / snext)
+  __device__ __forceinline__ float vmax(float ninv) const { return xmax * ninv; }
+};
+
+// maximum over the 16 lanes of a DPP row (all 16 lanes receive it): four VALU instructions, no LDS round trip
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_max16(float v) {       // v >= 0
+  v = fmaxf(v, dpp_f<0xB1>(v));      // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_f<0x4E>(v));      // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_f<0x141>(v));     // row_half_mirror
+  v = fmaxf(v, dpp_f<0x140>(v));     // row_mirror
+  return v;
+}
+// fold a lane's non-negative value into an LDS slot (float bits as unsigned).  Written as one ds_max_u32 from four lanes
+// in inline assembly: the compiler's atomic optimiser would turn a plain atomicMax into a 64-iteration scalar readlane loop.
+__device__ __forceinline__ void slot_max(unsigned* slot, float v, int lane) {
+  v = row_max16(v);
+  if ((lane & 15) == 0) {
+    const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)slot;
+    asm volatile("ds_max_u32 %0, %1" ::"v"(a), "v"(__float_as_uint(v)) : "memory");
+  }
+}
+__device__ __forceinline__ float slot_get(const unsigned* slot) { return __uint_as_float(*slot); }
+
+// bias of the 16 features a lane holds (fb + 8 q + c); zero unless `keep`
+__device__ __forceinline__ void load_bias16(float (&b)[16], const float* __restrict__ bias, int fb, bool keep) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(bias + fb + 8 * q);
+    b[4 * q] = keep ? v.x : 0.f; b[4 * q + 1] = keep ? v.y : 0.f; b[4 * q + 2] = keep ? v.z : 0.f; b[4 * q + 3] = keep ? v.w : 0.f;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ warp net, forward
+// Same contract as k_warp_fused_fwd: pts[M][3] -> out[M][4][4], hidden activations X0..X3 ([4M][128] fp32 each) for backward.
+__global__ __launch_bounds__(256) void k_warp_fused_fwd_s(const float* __restrict__ params, const float* __restrict__ pts,
+                                                          const int32_t* __restrict__ count, int capacity, float out_range,
+                                                          float* __restrict__ acts, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) _Float16 At[2][2 * PLANE];      // tile 1 doubles as the fp32 [64][LDA] view
+  __shared__ __attribute__((aligned(16))) float W4s[4 * LDA];
+  __shared__ __attribute__((aligned(16))) float Red[4 * 64 * 4];
+  __shared__ float Ps[2][52];                                              // 48 coordinates + max |.| of each 16 at [48..50]
+  __shared__ unsigned Mx[2][8];                                            // maxima of (X0, X1, X2) x (half 0, half 1), two parities
+  __shared__ float red4[4];
+  __shared__ __attribute__((aligned(16))) float Bs[4][128];                // hidden-layer biases, row 3 = zeros
+  static_assert(2 * PLANE * 2 >= TILE_ROWS * LDA * 4, "fp32 view must fit into a split tile");
+  const int M = min(count[0], capacity);
+  const int R = 4 * M;
+  const int ntiles = (M + 15) >> 4;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int col = wid * 32 + l31;                    // feature whose weights this lane holds (A operand)
+  const int fb = wid * 32 + 4 * lh;                  // first of the features this lane holds in the accumulators
+  const bool primal = (l31 & 3) == 0;
+  const size_t LS = (size_t)capacity * 4 * 128;
+
+  SplitW w1, w2, w3;
+  float l1_1, l1_2, l1_3;
+  const int ew1 = load_w_rows_split(w1, l1_1, params + WPF_W1, col, lh, red4, tid);
+  const int ew2 = load_w_rows_split(w2, l1_2, params + WPF_W2, col, lh, red4, tid);
+  const int ew3 = load_w_rows_split(w3, l1_3, params + WPF_W3, col, lh, red4, tid);
+  // biases of the hidden layers in LDS: row l = the layer's biases, row 3 = zeros (tangent lanes, and the input layer whose
+  // bias rides in the product); a lane reads its four runs of four from `brow(l)`
+  if (tid < 128) { Bs[0][tid] = params[WPF_B1 + tid]; Bs[1][tid] = params[WPF_B2 + tid]; Bs[2][tid] = params[WPF_B3 + tid]; Bs[3][tid] = 0.f; }
+  auto brow = [&](int l) -> const float* { return &Bs[primal ? l : 3][fb]; };
+  const float b1mx = block_max(fabsf(params[WPF_B1 + col]), red4, tid), b2mx = block_max(fabsf(params[WPF_B2 + col]), red4, tid);
+  // input layer as a K = 16 product: A = [w0x w0y w0z b0 0 ...] (lanes lh = 0), B = [px py pz 1 0 ...] / unit tangents
+  const float w0x = params[WPF_W0 + col * 3], w0y = params[WPF_W0 + col * 3 + 1], w0z = params[WPF_W0 + col * 3 + 2];
+  const float b0 = params[WPF_B0 + col];
+  const float w0l1 = block_max((fabsf(w0x) + fabsf(w0y)) + fabsf(w0z), red4, tid) * 1.0001f;
+  const float w0mx = block_max(fmaxf(fmaxf(fabsf(w0x), fabsf(w0y)), fabsf(w0z)), red4, tid);
+  const float b0mx = block_max(fabsf(b0), red4, tid);
+  const int ew0 = scale_exp(fmaxf(w0mx, b0mx));
+  pp_half8 a0h, a0l;
+  {
+    const float z = 0.f;
+    const float4 wa = lh == 0 ? make_float4(w0x, w0y, w0z, b0) : make_float4(z, z, z, z);
+    split8(wa, make_float4(z, z, z, z), pow2(ew0), a0h, a0l);
+  }
+  for (int i = tid; i < 512; i += 256) W4s[(i >> 7) * LDA + (i & 127)] = params[WPF_W4 + i];
+  const float b4 = (((tid >> 2) & 3) == 0) ? params[WPF_B4 + (tid & 3)] : 0.f;   // bias on the primal row only
+  // positions of a tile are fetched one tile ahead and parked in LDS together with their largest magnitudes (wave 0)
+  auto park = [&](int slot, float p) {
+    if (wid == 0) {
+      const float m = row_max16(fabsf(p));
+      if (lane < 48) Ps[slot][lane] = p;
+      if ((lane & 15) == 0 && lane < 48) Ps[slot][48 + (lane >> 4)] = m;
+    }
+  };
+  float pnext = 0.f;
+  if (tid < 48 && (int)blockIdx.x * 48 + tid < M * 3) pnext = pts[blockIdx.x * 48 + tid];
+  park(0, pnext);
+  if (tid < 16) Mx[tid >> 3][tid & 7] = 0u;
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+#ifdef MS_TIMERS
+  unsigned long long tsum[16] = {0}, tprev = __builtin_readcyclecounter();
+#endif
+  int par = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
+    const int s0 = tile * 16, r0 = tile * TILE_ROWS;
+    TICK(15);
+    {
+      const int nt = tile + gridDim.x;
+      pnext = 0.f;
+      if (tid < 48 && nt < ntiles && nt * 48 + tid < M * 3) pnext = pts[nt * 48 + tid];
+    }
+    const bool ok0 = r0 + l31 < R, ok1 = r0 + 32 + l31 < R;
+    float* __restrict__ crow = acts + (size_t)(r0 + l31) * 128 + fb;           // this lane's row of half 0 in X0
+    _Float16* const arow0 = &At[0][l31 * LDH2 + fb];                            // ... in LDS tile 0 / 1
+    _Float16* const arow1 = &At[1][l31 * LDH2 + fb];
+    float* const frow1 = reinterpret_cast<float*>(At[1]) + l31 * LDA + fb;      // fp32 view of tile 1
+    f32x16 acc0, acc1;
+    // ---- layer 0 (3 -> 128), 4-row form: row 4s = W0 [p, 1], rows 4s+1.. = W0 e_i (gated by the primal row's state)
+    const float pmx = fmaxf(fmaxf(Ps[par][48], Ps[par][49]), Ps[par][50]);
+    const int ein = scale_exp(fmaxf(pmx, 1.f));
+    const int e0 = scale_exp(fmaxf(fmaf(w0l1, pmx, b0mx), w0mx));
+    const float sin = pow2(ein), sc0 = pow2(e0);
+    auto layer0 = [&](int t, f32x16& acc) {
+      const int sl = 8 * t + (l31 >> 2), c = l31 & 3;                      // sample of this lane's row, row kind
+      const bool valid = s0 + sl < M && lh == 0;
+      const float px = Ps[par][sl * 3], py = Ps[par][sl * 3 + 1], pz = Ps[par][sl * 3 + 2];
+      float4 x = make_float4(c == 0 ? px : (c == 1 ? 1.f : 0.f), c == 0 ? py : (c == 2 ? 1.f : 0.f),
+                             c == 0 ? pz : (c == 3 ? 1.f : 0.f), c == 0 ? 1.f : 0.f);
+      if (!valid) x = make_float4(0.f, 0.f, 0.f, 0.f);
+      pp_half8 xh, xl;
+      split8(x, make_float4(0.f, 0.f, 0.f, 0.f), sin, xh, xl);
+      zero16(acc);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, xl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, xh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, xh, acc, 0, 0, 0);
+    };
+    layer0(0, acc0);
+    layer0(1, acc1);
+    const float inv0 = pow2(-(ein + ew0)), ninv0 = pow2(-e0);
+    HalfEpilogue<4, true> ea;          // epilogue state of the half that is being written out
+    ea.begin(brow(3));
+    ea.all(acc0, inv0, sc0, ok0, crow, arow0);
+    slot_max(&Mx[par][0], ea.vmax(ninv0), lane);
+    TICK(0);
+    __syncthreads();
+    TICK(1);
+    if (tid < 8) Mx[par ^ 1][tid] = 0u;                   // the next tile's slots (last read a tile ago)
+    // ---- stage A1: layer 1 on half 0  ||  epilogue of (layer 0, half 1)
+    zero16(acc0);
+    ea.begin(brow(3));
+    mma_half(&At[0][0], w1, acc0, l31, lh, [&](int ks) { ea.step(ks, acc1, inv0, sc0, ok1, crow + 32 * 128, arow0 + 32 * LDH2); });
+    slot_max(&Mx[par][1], ea.vmax(ninv0), lane);
+    park(par ^ 1, pnext);                                  // next tile's positions (read after >= 3 barriers)
+    TICK(2);
+    __syncthreads();
+    TICK(3);
+    // ---- stage B1: layer 1 on half 1  ||  epilogue of (layer 1, half 0)
+    const int e10 = scale_exp(fmaf(slot_get(&Mx[par][0]), l1_1, b1mx));
+    const float sc10 = pow2(e10), inv1 = pow2(-(e0 + ew1));
+    zero16(acc1);
+    ea.begin(brow(0));
+    mma_half(&At[0][32 * LDH2], w1, acc1, l31, lh, [&](int ks) { ea.step(ks, acc0, inv1, sc10, ok0, crow + LS, arow1); });
+    slot_max(&Mx[par][2], ea.vmax(pow2(-e10)), lane);
+    TICK(4);
+    __syncthreads();
+    TICK(5);
+    // ---- stage A2: layer 2 on half 0  ||  epilogue of (layer 1, half 1)
+    const int e11 = scale_exp(fmaf(slot_get(&Mx[par][1]), l1_1, b1mx));
+    const float sc11 = pow2(e11);
+    zero16(acc0);
+    ea.begin(brow(0));
+    mma_half(&At[1][0], w2, acc0, l31, lh, [&](int ks) { ea.step(ks, acc1, inv1, sc11, ok1, crow + LS + 32 * 128, arow1 + 32 * LDH2); });
+    slot_max(&Mx[par][3], ea.vmax(pow2(-e11)), lane);
+    TICK(6);
+    __syncthreads();
+    TICK(7);
+    // ---- stage B2: layer 2 on half 1  ||  epilogue of (layer 2, half 0)
+    const int e20 = scale_exp(fmaf(slot_get(&Mx[par][2]), l1_2, b2mx));
+    const float sc20 = pow2(e20), inv20 = pow2(-(e10 + ew2)), inv21 = pow2(-(e11 + ew2));
+    zero16(acc1);
+    ea.begin(brow(1));
+    mma_half(&At[1][32 * LDH2], w2, acc1, l31, lh, [&](int ks) { ea.step(ks, acc0, inv20, sc20, ok0, crow + 2 * LS, arow0); });
+    TICK(8);
+    __syncthreads();
+    TICK(9);
+    // ---- stage A3: layer 3 on half 0  ||  epilogue of (layer 2, half 1)
+    const int e21 = scale_exp(fmaf(slot_get(&Mx[par][3]), l1_2, b2mx));
+    const float sc21 = pow2(e21);
+    zero16(acc0);
+    ea.begin(brow(1));
+    mma_half(&At[0][0], w3, acc0, l31, lh, [&](int ks) { ea.step(ks, acc1, inv21, sc21, ok1, crow + 2 * LS + 32 * 128, arow0 + 32 * LDH2); });
+    TICK(10);
+    __syncthreads();
+    TICK(11);
+    // ---- stage B3: layer 3 on half 1  ||  epilogue of (layer 3, half 0) into the fp32 view, then that of half 1
+    HalfEpilogue<4, false> ef;
+    const float inv30 = pow2(-(e20 + ew3)), inv31 = pow2(-(e21 + ew3));
+    zero16(acc1);
+    ef.begin(brow(2));
+    mma_half(&At[0][32 * LDH2], w3, acc1, l31, lh, [&](int ks) { ef.step(ks, acc0, inv30, 1.f, ok0, crow + 3 * LS, reinterpret_cast<_Float16*>(frow1)); });
+    ef.begin(brow(2));
+    ef.all(acc1, inv31, 1.f, ok1, crow + 3 * LS + 32 * 128, reinterpret_cast<_Float16*>(frow1 + 32 * LDA));
+    TICK(12);
+    __syncthreads();
+    TICK(13);
+    // ---- output layer (128 -> 4) on v_mfma_f32_4x4x1, fp32 view of tile 1 (as in k_warp_fused_fwd)
+    {
+      const float* As1 = reinterpret_cast<const float*>(At[1]);
+      const float* xr = &As1[lane * LDA + 32 * wid];
+      const float* wr = &W4s[(lane & 3) * LDA + 32 * wid];
+      float4 xv[8], wv[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        xv[g] = *reinterpret_cast<const float4*>(xr + 4 * g);
+        wv[g] = *reinterpret_cast<const float4*>(wr + 4 * g);
+      }
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].x, wv[g].x, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].y, wv[g].y, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].z, wv[g].z, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].w, wv[g].w, d1, 0, 0, 0);
+      }
+      *reinterpret_cast<float4*>(&Red[(wid * 64 + lane) * 4]) = make_float4(d0[0] + d1[0], d0[1] + d1[1], d0[2] + d1[2], d0[3] + d1[3]);
+    }
+    __syncthreads();
+    {
+      const int row = tid >> 2, o = tid & 3;
+      const int idx = ((row >> 2) * 4 + o) * 4 + (row & 3);
+      const float sum = (Red[idx] + Red[256 + idx]) + (Red[512 + idx] + Red[768 + idx]);
+      if (r0 + row < R) out[(size_t)r0 * 4 + tid] = (sum + b4) * out_range;
+    }
+    TICK(14);
+    // the next tile's first barrier orders these reads of tile 1 / Red before they are overwritten
+  }
+#ifdef MS_TIMERS
+  if (tid == 0)
+    for (int i = 0; i < 16; ++i) atomicAdd(&g_ms_t[i], tsum[i]);
+#endif
+}
+
+int pp_launch_warp_fused_fwd_s(const float* params, const float* pts, const int32_t* count, int capacity, float out_range,
+                               float* acts, float* out, hipStream_t st) {
+  const int ntiles = pp_div_up(capacity, 16);
+  const int grid = ntiles < PP_FUSED_WGS ? ntiles : PP_FUSED_WGS;
+  hipLaunchKernelGGL(k_warp_fused_fwd_s, dim3(grid), dim3(256), 0, st, params, pts, count, capacity, out_range, acts, out);
+  return 0;
+}

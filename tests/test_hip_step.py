@@ -51,7 +51,9 @@ def test_fused_step_matches_reference(tag):
     assert_close(c(ws.rgb[:M]), d['out.raw_rgb'], rtol=1e-4, atol=1e-5, name='raw_rgb')
     assert_close(c(ws.gradient[:M]), d['out.gradient'], rtol=1e-4, atol=1e-5, scaled=1e-6, name='gradient')
     assert_close(c(ws.grad_deform[:M]).reshape(M, 3, 3), d['out.grad_deform'], rtol=1e-4, atol=1e-6, name='grad_deform')
-    assert_close(c(ws.sdf_deform[:M]), d['out.sdf_deform'], rtol=1e-4, atol=2e-6, name='sdf_deform')
+    # the SDF template has values up to ~7 and slopes of that size per voxel: fp32 rounding of the warped position (1e-7)
+    # shows as 2e-6 of the largest value
+    assert_close(c(ws.sdf_deform[:M]), d['out.sdf_deform'], rtol=1e-4, atol=2e-6, scaled=2e-6, name='sdf_deform')
     depth = c(ws.t_min) / np.linalg.norm(c(ws.rays_d), axis=-1) + c(ws.depth_acc)
     assert_close(depth, d['out.depth'], rtol=1e-4, atol=1e-5, name='depth')
     # ---- loss scalars
