@@ -481,10 +481,13 @@ extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* a
   const size_t LS = (size_t)rcap * 128;
   if (mlp_fused_enabled()) {
     // one fused data-gradient kernel (+ thin layers), then the three weight-gradient GEMMs on the Ybar it left behind
-    pp_launch_warp_fused_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad, st);
+    if (pp_opt(PP_OPT_MLP_SPLIT) & 2) pp_launch_warp_fused_bwd_s(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad, st);
+    else pp_launch_warp_fused_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad, st);
     hipStream_t ws = deferred_fork(ctx, st);
+    const bool sb = (pp_opt(PP_OPT_MLP_SPLIT) & 2) != 0;   // the split-precision data-gradient kernel leaves b1..b3 to this one
     pp_launch_wgrad_chain(scratch, acts + 2 * LS, params_grad + WP_W3, scratch + LS, acts + LS, params_grad + WP_W2,
-                          scratch + 2 * LS, acts, params_grad + WP_W1, 128, count, 4, rcap, ws);
+                          scratch + 2 * LS, acts, params_grad + WP_W1, 128, count, 4, rcap, ws,
+                          sb ? params_grad + WP_B3 : nullptr, sb ? params_grad + WP_B2 : nullptr, sb ? params_grad + WP_B1 : nullptr);
     deferred_forked(ctx, ws, st);
     PP_CHECK_LAUNCH();
     return PP_OK;
@@ -533,8 +536,12 @@ extern "C" int pp_warp_bwd_data(const float* params, const float* pts, const flo
   PP_REQUIRE(params && pts && acts && out_grad && count && scratch && params_grad && pts_grad, "null pointer");
   PP_REQUIRE(capacity > 0, "capacity<=0");
   if (!mlp_fused_enabled()) { pp_set_error("pp_warp_bwd_data: option mlp_fused = 0 has no two-stage form"); return PP_ERR_UNSUPPORTED; }
-  pp_launch_warp_fused_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad,
-                           pp_stream(stream));
+  if (pp_opt(PP_OPT_MLP_SPLIT) & 2)
+    pp_launch_warp_fused_bwd_s(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad,
+                               pp_stream(stream));
+  else
+    pp_launch_warp_fused_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad,
+                             pp_stream(stream));
   PP_CHECK_LAUNCH();
   return PP_OK;
 }
@@ -546,8 +553,10 @@ extern "C" int pp_warp_bwd_weights(const float* acts, const float* scratch, cons
   if (!mlp_fused_enabled()) { pp_set_error("pp_warp_bwd_weights: option mlp_fused = 0 has no two-stage form"); return PP_ERR_UNSUPPORTED; }
   const int rcap = capacity * 4;
   const size_t LS = (size_t)rcap * 128;
+  const bool sb = (pp_opt(PP_OPT_MLP_SPLIT) & 2) != 0;     // see pp_warp_bwd
   pp_launch_wgrad_chain(scratch, acts + 2 * LS, params_grad + WP_W3, scratch + LS, acts + LS, params_grad + WP_W2,
-                        scratch + 2 * LS, acts, params_grad + WP_W1, 128, count, 4, rcap, pp_stream(stream));
+                        scratch + 2 * LS, acts, params_grad + WP_W1, 128, count, 4, rcap, pp_stream(stream),
+                        sb ? params_grad + WP_B3 : nullptr, sb ? params_grad + WP_B2 : nullptr, sb ? params_grad + WP_B1 : nullptr);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }

@@ -28,10 +28,14 @@ int pp_launch_warp_fused_bwd(const float* params, const float* pts, const float*
 // split-precision variants (pp_mlp_split.hip, option "mlp_split"): same contracts
 int pp_launch_warp_fused_fwd_s(const float* params, const float* pts, const int32_t* count, int capacity, float out_range,
                                float* acts, float* out, hipStream_t st);
-// weight gradients of three layers (Y_l^T X_l accumulated into W_l) in one persistent kernel; kxc = width of X of layer C
+int pp_launch_warp_fused_bwd_s(const float* params, const float* pts, const float* acts, const float* out_grad,
+                               const int32_t* count, int capacity, float out_range, float* ybar, float* params_grad,
+                               float* pts_grad, hipStream_t st);
+// weight gradients of three layers (Y_l^T X_l accumulated into W_l) in one persistent kernel; kxc = width of X of layer C;
+// bA / bB / bC (warp net, rmul == 4 only): also accumulate the bias gradients = column sums of Y over the primal rows
 int pp_launch_wgrad_chain(const float* YA, const float* XA, float* WA, const float* YB, const float* XB, float* WB,
                           const float* YC, const float* XC, float* WC, int kxc, const int32_t* count, int rmul, int rcap,
-                          hipStream_t st);
+                          hipStream_t st, float* bA = nullptr, float* bB = nullptr, float* bC = nullptr);
 
 // parameter block of rgbnet (64-wide padded input): W0[128x64] b0 | W1[128x128] b1 | W2[128x128] b2 | W3[3x128] b3
 #define RGF_W0 0

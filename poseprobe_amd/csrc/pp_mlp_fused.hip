@@ -573,6 +573,8 @@ struct WgradLayer {
   const float* Y;      // [R][128]   gradient w.r.t. the layer's pre-activation (already gated)
   const float* X;      // [R][KX]    input activations of the layer
   float* Wbar;         // [128][KX]
+  float* bbar;         // [128] or nullptr: += column sums of Y over every FOURTH row (the primal rows of the warp net's 4-row form);
+                       // used when the data-gradient kernel leaves the hidden-layer bias gradients to this one (pp_mlp_split.hip)
 };
 
 namespace {
@@ -697,6 +699,15 @@ __global__ __launch_bounds__(256) void k_wgrad_chain(WgradLayer LA, WgradLayer L
   // Six steps per iteration keep the buffer assignment static: A0 B1 C0 | A1 B0 C1.  The unit of work is a PAIR of
   // adjacent tiles, so only the very last pair can contain an empty tile (rows clamped, Y zeroed by fix_tail);
   // straight-line control flow keeps the 192 accumulator registers pinned across the hand-scheduled blocks.
+  // optional bias gradients: thread = (feature tid & 127, row half tid >> 7); rows past R are zero in LDS (fix_tail)
+  float bA = 0.f, bB = 0.f, bC = 0.f;
+  auto colsum = [&](const float* Ybuf) {
+    const float* p = Ybuf + (tid >> 7) * 32 * 128 + (tid & 127);
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; r += 4) sum += p[r * 128];
+    return sum;
+  };
   const int npairs = (ntiles + 1) >> 1;
   // Tiles are walked from the END of the row range: the backward-data kernel that just ran wrote Ybar front to back, so its
   // most recent output is what the 256 MB Infinity Cache still holds.
@@ -707,26 +718,35 @@ __global__ __launch_bounds__(256) void k_wgrad_chain(WgradLayer LA, WgradLayer L
     const int t2 = pair + gridDim.x;
     PP_WAIT_VMEM(); __syncthreads();
     fix_tail(r0, Yb0);
+    if (LA.bbar) bA += colsum(Yb0);
     wgrad_step<128, 128>(true, LB, r0, R, Yb1, Xb1, Yb0, Xb0, accA, wid, lane);
     PP_WAIT_VMEM(); __syncthreads();
     fix_tail(r0, Yb1);
+    if (LB.bbar) bB += colsum(Yb1);
     wgrad_step<KXC, 128>(true, LC, r0, R, Yb0, Xb0, Yb1, Xb1, accB, wid, lane);
     PP_WAIT_VMEM(); __syncthreads();
     fix_tail(r0, Yb0);
+    if (LC.bbar) bC += colsum(Yb0);
     wgrad_step<128, KXC>(true, LA, r1, R, Yb1, Xb1, Yb0, Xb0, accC, wid, lane);
     PP_WAIT_VMEM(); __syncthreads();
     fix_tail(r1, Yb1);
+    if (LA.bbar) bA += colsum(Yb1);
     wgrad_step<128, 128>(true, LB, r1, R, Yb0, Xb0, Yb1, Xb1, accA, wid, lane);
     PP_WAIT_VMEM(); __syncthreads();
     fix_tail(r1, Yb0);
+    if (LB.bbar) bB += colsum(Yb0);
     wgrad_step<KXC, 128>(true, LC, r1, R, Yb1, Xb1, Yb0, Xb0, accB, wid, lane);
     PP_WAIT_VMEM(); __syncthreads();
     fix_tail(r1, Yb1);
+    if (LC.bbar) bC += colsum(Yb1);
     wgrad_step<128, KXC>(t2 < npairs, LA, (npairs - 1 - t2) * 2 * TILE_ROWS, R, Yb0, Xb0, Yb1, Xb1, accC, wid, lane);
   }
   wgrad_flush<128>(LA.Wbar, accA, wr, wc, l31, lh);
   wgrad_flush<128>(LB.Wbar, accB, wr, wc, l31, lh);
   wgrad_flush<KXC>(LC.Wbar, accC, wr, wc, l31, lh);
+  if (LA.bbar) atomicAdd(&LA.bbar[tid & 127], bA);
+  if (LB.bbar) atomicAdd(&LB.bbar[tid & 127], bB);
+  if (LC.bbar) atomicAdd(&LC.bbar[tid & 127], bC);
 }
 
 // option "wgrad_split" = 1 replaces the fp32-instruction chain kernel above by three launches of the self-scaling split-precision
@@ -737,8 +757,8 @@ static bool wgrad_split_enabled() { return pp_opt(PP_OPT_WGRAD_SPLIT) == 1; }
 
 int pp_launch_wgrad_chain(const float* YA, const float* XA, float* WA, const float* YB, const float* XB, float* WB,
                           const float* YC, const float* XC, float* WC, int kxc, const int32_t* count, int rmul, int rcap,
-                          hipStream_t st) {
-  if (wgrad_split_enabled()) {
+                          hipStream_t st, float* bA, float* bB, float* bC) {
+  if (wgrad_split_enabled() && !bA) {
     // three launches of the self-scaling split-precision kernel (pp_gemm_split.h): three fp16 products per fp32 product,
     // error against fp64 equal to the fp32 matrix instructions'; load-bound instead of matrix-pipe bound
     const int splits = rcap >= 131072 ? 256 : 128;
@@ -747,7 +767,7 @@ int pp_launch_wgrad_chain(const float* YA, const float* XA, float* WA, const flo
     hipLaunchKernelGGL(k_gemm_tn_split_auto, dim3(splits), dim3(256), 0, st, YC, XC, kxc, kxc, WC, kxc, count, rmul, rcap);
     return 0;
   }
-  WgradLayer LA{YA, XA, WA}, LB{YB, XB, WB}, LC{YC, XC, WC};
+  WgradLayer LA{YA, XA, WA, bA}, LB{YB, XB, WB, bB}, LC{YC, XC, WC, bC};
   const int npairs = pp_div_up(rcap, 2 * TILE_ROWS);
   const int grid = npairs < PP_FUSED_WGS ? npairs : PP_FUSED_WGS;
   if (kxc == 128)

@@ -492,3 +492,406 @@ int pp_launch_warp_fused_fwd_s(const float* params, const float* pts, const int3
   hipLaunchKernelGGL(k_warp_fused_fwd_s, dim3(grid), dim3(256), 0, st, params, pts, count, capacity, out_range, acts, out);
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ warp net, backward
+// Same contract as k_warp_fused_bwd (pp_mlp_fused.hip): data-gradient chain Ybar3 -> Ybar2 -> Ybar1 -> Ybar0 with the transposed
+// weights stationary, the output layer's backward (Ybar3, W4bar, b4bar), the input layer's backward (pts_grad, W0bar, b0bar) and
+// all bias gradients; Ybar3 / Ybar2 / Ybar1 go to `ybar` ([3][4 cap][128] fp32) for the weight-gradient kernel.
+// Differences to the forward kernel above: the epilogue gates by the STORED activation of the layer's input (primal row of the
+// quad, staged by LDS-direct loads one stage ahead into GT) instead of a quad broadcast, there is no bias, and the lanes
+// accumulate the bias gradients (lane = row, so the per-feature sums are reduced over the primal lanes once, at the end).
+// Everything in a tile is linear in out_grad, so the scale of the first image (from the tile's largest |out_grad|) would do for
+// all of them; the per-half maxima are tracked anyway, which keeps the bounds one product deep.
+namespace {
+
+// transposed weights of input feature j (A operand of the data-gradient product): k = n = 16 ks + 8 lh + jj, value W[n][j].
+// Returns the exponent of the layer's scale; l1 = max_j sum_n |W[n][j]|.
+__device__ __forceinline__ int load_w_cols_split(SplitW& w, float& l1, const float* __restrict__ W, int j, int lh, float* red, int tid) {
+  float4 v[16];
+  float mx = 0.f, sum = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const float* p = W + (size_t)(16 * ks + 8 * lh) * 128 + j;
+    v[2 * ks] = make_float4(p[0], p[128], p[256], p[384]);
+    v[2 * ks + 1] = make_float4(p[512], p[640], p[768], p[896]);
+    mx = fmaxf(mx, fmaxf(amax4(v[2 * ks]), amax4(v[2 * ks + 1])));
+    sum += asum4(v[2 * ks]) + asum4(v[2 * ks + 1]);
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  const int e = scale_exp(block_max(mx, red, tid));
+  const float s = pow2(e);
+  l1 = block_max(sum, red, tid) * 1.0001f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) split8(v[2 * ks], v[2 * ks + 1], s, w.h[ks], w.l[ks]);
+  return e;
+}
+
+// Epilogue of one 32-row half of a data-gradient product, eight batched steps (see HalfEpilogue): v = gate ? acc * inv : 0 with
+// gate = stored activation of the quad's primal row > 0 (grow: that row in GT / XS + fb), fp32 copy to HBM (`ok` rows;
+// Crow == nullptr: none), next tile to LDS as a split image (SPLIT) or as the fp32 view.  The bias gradients of the hidden layers
+// (column sums of Ybar over the primal rows) are NOT formed here - with lane = row they would cost 48 accumulator registers and
+// a cross-lane reduction; the weight-gradient kernel, which has every Ybar tile in LDS anyway, adds them (pp_launch_wgrad_chain).
+template <bool SPLIT>
+struct HalfEpilogueB {
+  float4 g[4];
+  float y[16], p[16];
+  unsigned h[8], l[8];
+  unsigned long long m[16];
+  float xmax;
+  __device__ __forceinline__ void begin(const float* __restrict__ grow) {
+    xmax = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = *reinterpret_cast<const float4*>(grow + 8 * q);
+  }
+  __device__ __forceinline__ void step(int i, const f32x16& acc, float inv, float snext, bool ok, float* __restrict__ Crow,
+                                       _Float16* __restrict__ Arow) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (i == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) y[e] = acc[e] * inv;
+    } else if (i == 1) {
+      // gates into sixteen SGPR pairs, consumed a step later: no VCC round trip between a compare and its select
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        asm volatile("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(m[4 * q]) : "v"(g[q].x));
+        asm volatile("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(m[4 * q + 1]) : "v"(g[q].y));
+        asm volatile("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(m[4 * q + 2]) : "v"(g[q].z));
+        asm volatile("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(m[4 * q + 3]) : "v"(g[q].w));
+      }
+    } else if (i == 2) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) asm volatile("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(y[e]) : "v"(y[e]), "s"(m[e]));
+    } else if (i == 3) {
+      if (Crow != nullptr && ok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(Crow + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+      }
+      if (!SPLIT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(Arow) + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+      }
+    } else if (SPLIT && i == 4) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) p[e] = y[e] * snext;
+    } else if (SPLIT && i == 5) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h[k]) : "v"(p[2 * k]), "v"(p[2 * k + 1]));
+        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(xmax) : "v"(p[2 * k]), "v"(p[2 * k + 1]));
+      }
+    } else if (SPLIT && i == 6) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l[k]) : "v"(h[k]), "v"(p[2 * k]));
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[k]) : "v"(h[k]), "v"(p[2 * k + 1]));
+    } else if (SPLIT && i == 7) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<uint2*>(Arow + 8 * q) = make_uint2(h[2 * q], h[2 * q + 1]);
+        *reinterpret_cast<uint2*>(Arow + 8 * q + PLANE) = make_uint2(l[2 * q], l[2 * q + 1]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void all(const f32x16& acc, float inv, float snext, bool ok, float* __restrict__ Crow, _Float16* __restrict__ Arow) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) step(i, acc, inv, snext, ok, Crow, Arow);
+  }
+  __device__ __forceinline__ float vmax(float ninv) const { return xmax * ninv; }
+};
+
+#define PP_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define PP_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_warp_fused_bwd_s(const float* __restrict__ params, const float* __restrict__ pts,
+                                                          const float* __restrict__ acts, const float* __restrict__ out_grad,
+                                                          const int32_t* __restrict__ count, int capacity, float out_range,
+                                                          float* __restrict__ ybar, float* __restrict__ params_grad,
+                                                          float* __restrict__ pts_grad) {
+  __shared__ __attribute__((aligned(16))) _Float16 At[2][2 * PLANE];      // tile 1 doubles as the fp32 [64][LDA] view (Ybar0)
+  __shared__ __attribute__((aligned(16))) float XS[TILE_ROWS * 128];      // X3 rows of the NEXT tile (unpadded, lane-contiguous)
+  __shared__ __attribute__((aligned(16))) float GT[2][16 * 128];          // primal rows of the gating activation of a layer
+  __shared__ __attribute__((aligned(16))) float W0s[4 * LDA];
+  __shared__ __attribute__((aligned(16))) float G[2][256];                // raw out_grad of the current / next tile
+  __shared__ __attribute__((aligned(16))) float Ps[2][64];                // sample positions of the current / next tile
+  __shared__ __attribute__((aligned(16))) float Red[4 * 64];
+  __shared__ unsigned Mx[2][8];      // per parity: max |Ybar3| (halves 0, 1), |Ybar2| (0, 1), |Ybar1| (0, 1), max |out_grad| of the tile
+  __shared__ float red4[4];
+  const int M = min(count[0], capacity);
+  const int R = 4 * M;
+  const int ntiles = (M + 15) >> 4;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int col = wid * 32 + l31;
+  const int fb = wid * 32 + 4 * lh;
+  const int pr = l31 >> 2;                            // primal row (sample) of this lane's quad inside a 32-row half
+  const size_t LS = (size_t)capacity * 4 * 128;
+  const float* __restrict__ X0 = acts;
+  const float* __restrict__ X1 = acts + LS;
+  const float* __restrict__ X2 = acts + 2 * LS;
+  const float* __restrict__ X3 = acts + 3 * LS;
+
+  SplitW w3, w2, w1;
+  float l1_3, l1_2, l1_1;
+  const int ew3 = load_w_cols_split(w3, l1_3, params + WPF_W3, col, lh, red4, tid);
+  const int ew2 = load_w_cols_split(w2, l1_2, params + WPF_W2, col, lh, red4, tid);
+  const int ew1 = load_w_cols_split(w1, l1_1, params + WPF_W1, col, lh, red4, tid);
+  // output layer backward as a K = 16 product: A = [w4_0 w4_1 w4_2 w4_3 0 ...] * out_range of feature `col` (lanes lh = 0),
+  // B = the row's four out_grad entries
+  const float w4a = params[WPF_W4 + col] * out_range, w4b = params[WPF_W4 + 128 + col] * out_range,
+              w4c = params[WPF_W4 + 256 + col] * out_range, w4d = params[WPF_W4 + 384 + col] * out_range;
+  const float w4l1 = block_max((fabsf(w4a) + fabsf(w4b)) + (fabsf(w4c) + fabsf(w4d)), red4, tid) * 1.0001f;
+  const int ew4 = scale_exp(block_max(fmaxf(fmaxf(fabsf(w4a), fabsf(w4b)), fmaxf(fabsf(w4c), fabsf(w4d))), red4, tid));
+  pp_half8 a4h, a4l;
+  {
+    const float z = 0.f;
+    const float4 wa = lh == 0 ? make_float4(w4a, w4b, w4c, w4d) : make_float4(z, z, z, z);
+    split8(wa, make_float4(z, z, z, z), pow2(ew4), a4h, a4l);
+  }
+  const int j0 = tid & 127, h0 = tid >> 7;
+  for (int i = tid; i < 512; i += 256) {
+    const int r = i >> 7, j = i & 127;
+    W0s[r * LDA + j] = (r < 3) ? params[WPF_W0 + j * 3 + r] : 0.f;
+  }
+  float wacc4[4] = {0.f, 0.f, 0.f, 0.f}, bacc4 = 0.f, wacc0[3] = {0.f, 0.f, 0.f}, bacc0 = 0.f;
+
+  // ---- LDS-direct staging of tile t into parity slot b: X3 rows -> XS, out_grad -> G[b], positions -> Ps[b] (10 pieces);
+  // rows / samples past the end are clamped, their out_grad slot is zeroed after the wait
+  auto stage_piece = [&](int t, int b, int i) {
+    const int rn0 = t * TILE_ROWS, sn0 = t * 16;
+    if (i < 8) {
+      const int rl = 16 * wid + 2 * i;
+      const int row = min(rn0 + rl + lh, R - 1);
+      __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(X3 + (size_t)row * 128 + l31 * 4), PP_LDS_PTR(&XS[rl * 128]), 16, 0, 0);
+    } else if (i == 8) {
+      const int e = min(sn0 * 16 + tid, M * 16 - 1);
+      __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(out_grad + e), PP_LDS_PTR(&G[b][wid * 64]), 4, 0, 0);
+    } else if (wid == 0) {
+      const int e = min(sn0 * 3 + lane, M * 3 - 1);
+      __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(pts + e), PP_LDS_PTR(&Ps[b][0]), 4, 0, 0);
+    }
+  };
+  // primal rows (every fourth) of activation X of tile rows r0.. -> GT[gb]: 16 rows x 512 B, two pieces per wavefront
+  auto stage_gate_piece = [&](const float* __restrict__ X, int r0, int gb, int i) {
+    const int prow = 4 * wid + 2 * i;
+    const int row = min(r0 + 4 * (prow + lh), R - 1);
+    __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(X + (size_t)row * 128 + l31 * 4), PP_LDS_PTR(&GT[gb][prow * 128]), 16, 0, 0);
+  };
+  // samples past M contribute nothing; largest |out_grad| of the tile into its slot
+  auto prepare_grad = [&](int t, int b) {
+    float gv = G[b][tid];
+    if (t * 16 + (tid >> 4) >= M) { gv = 0.f; G[b][tid] = 0.f; }
+    slot_max(&Mx[b][6], fabsf(gv), lane);
+  };
+  // W4bar / b4bar of the staged tile (thread = feature j0, rows of half h0)
+  auto w4_accumulate = [&](int b) {
+    const float* __restrict__ xs = &XS[(h0 * 32) * 128 + j0];
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      const float4 gq = *reinterpret_cast<const float4*>(&G[b][(h0 * 32 + r) * 4]);
+      const float x = xs[r * 128];
+      wacc4[0] = fmaf(gq.x, x, wacc4[0]); wacc4[1] = fmaf(gq.y, x, wacc4[1]);
+      wacc4[2] = fmaf(gq.z, x, wacc4[2]); wacc4[3] = fmaf(gq.w, x, wacc4[3]);
+      if (j0 < 4 && (r & 3) == 0) bacc4 += G[b][(h0 * 32 + r) * 4 + j0];
+    }
+  };
+  // Ybar3 (pre-gate) of half t of the staged tile: three MFMAs
+  auto out_layer = [&](int b, int t, float sg, f32x16& acc) {
+    float4 x = *reinterpret_cast<const float4*>(&G[b][(t * 32 + l31) * 4]);
+    if (lh != 0) x = make_float4(0.f, 0.f, 0.f, 0.f);
+    pp_half8 xh, xl;
+    split8(x, make_float4(0.f, 0.f, 0.f, 0.f), sg, xh, xl);
+    zero16(acc);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a4h, xl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a4l, xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a4h, xh, acc, 0, 0, 0);
+  };
+  // Ybar3 of the staged tile (parity b) into LDS tile 0 and `ybar`: both halves; returns the exponents of the two images
+  int e3n0 = 0, e3n1 = 0;
+  auto out_layer_bwd = [&](int t, int b) {
+    const float gmx = slot_get(&Mx[b][6]);
+    const int eg = scale_exp(gmx);
+    const int e3 = scale_exp(gmx * w4l1);
+    const float sg = pow2(eg), s3 = pow2(e3), inv = pow2(-(eg + ew4)), n3 = pow2(-e3);
+    const int r0 = t * TILE_ROWS;
+    f32x16 a0, a1;
+    out_layer(b, 0, sg, a0);
+    out_layer(b, 1, sg, a1);
+    HalfEpilogueB<true> eb;
+    float* crow = ybar + (size_t)(r0 + l31) * 128 + fb;
+    eb.begin(&XS[(4 * pr) * 128 + fb]);
+    eb.all(a0, inv, s3, r0 + l31 < R, crow, &At[0][l31 * LDH2 + fb]);
+    slot_max(&Mx[b][0], eb.vmax(n3), lane);
+    eb.begin(&XS[(32 + 4 * pr) * 128 + fb]);
+    eb.all(a1, inv, s3, r0 + 32 + l31 < R, crow + 32 * 128, &At[0][(32 + l31) * LDH2 + fb]);
+    slot_max(&Mx[b][1], eb.vmax(n3), lane);
+    e3n0 = e3; e3n1 = e3;
+  };
+
+  if (tid < 16) Mx[tid >> 3][tid & 7] = 0u;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) stage_piece(blockIdx.x, 0, i);
+  __builtin_amdgcn_s_waitcnt(0);        // all prologue loads landed
+  __syncthreads();
+  prepare_grad(blockIdx.x, 0);
+  __syncthreads();
+  w4_accumulate(0);
+  out_layer_bwd(blockIdx.x, 0);
+  __syncthreads();
+
+  int par = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
+    const int r0 = tile * TILE_ROWS, s0 = tile * 16;
+    const int tnext = tile + gridDim.x;
+    const bool more = tnext < ntiles;
+    const bool ok0 = r0 + l31 < R, ok1 = r0 + 32 + l31 < R;
+    const int e30 = e3n0, e31 = e3n1;                     // exponents of this tile's Ybar3 image (set by out_layer_bwd)
+    float* const crow = ybar + (size_t)(r0 + l31) * 128 + fb;
+    _Float16* const arow0 = &At[0][l31 * LDH2 + fb];
+    _Float16* const arow1 = &At[1][l31 * LDH2 + fb];
+    float* const frow1 = reinterpret_cast<float*>(At[1]) + l31 * LDA + fb;
+    const float* const grow0 = &GT[0][pr * 128 + fb];     // gate rows of half 0 (half 1: + 8 rows)
+    const float* const grow1 = &GT[1][pr * 128 + fb];
+    f32x16 acc0, acc1;
+    HalfEpilogueB<true> eb;
+    if (tid < 7) Mx[par ^ 1][tid] = 0u;                   // the next tile's slots
+    // ---- stage A3: layer 3 on half 0; loads: gates X2 -> GT[0], the next tile's X3 / out_grad / positions
+    zero16(acc0);
+    mma_half(&At[0][0], w3, acc0, l31, lh, [&](int ks) {
+      if (ks < 2) stage_gate_piece(X2, r0, 0, ks);
+      if (more) { stage_piece(tnext, par ^ 1, ks); if (ks < 2) stage_piece(tnext, par ^ 1, 8 + ks); }
+    });
+    PP_WAIT_VMEM();
+    __syncthreads();
+    // ---- stage B3: layer 3 on half 1  ||  epilogue of (Ybar2, half 0); loads: gates X1 -> GT[1]
+    const int e20 = scale_exp(slot_get(&Mx[par][0]) * l1_3), e21 = scale_exp(slot_get(&Mx[par][1]) * l1_3);
+    if (more) prepare_grad(tnext, par ^ 1);
+    zero16(acc1);
+    eb.begin(grow0);
+    mma_half(&At[0][32 * LDH2], w3, acc1, l31, lh, [&](int ks) {
+      if (ks < 2) stage_gate_piece(X1, r0, 1, ks);
+      eb.step(ks, acc0, pow2(-(e30 + ew3)), pow2(e20), ok0, crow + LS, arow1);
+    });
+    slot_max(&Mx[par][2], eb.vmax(pow2(-e20)), lane);
+    __syncthreads();
+    // ---- stage A2: layer 2 on half 0  ||  epilogue of (Ybar2, half 1)
+    zero16(acc0);
+    eb.begin(grow0 + 8 * 128);
+    mma_half(&At[1][0], w2, acc0, l31, lh, [&](int ks) {
+      eb.step(ks, acc1, pow2(-(e31 + ew3)), pow2(e21), ok1, crow + LS + 32 * 128, arow1 + 32 * LDH2);
+    });
+    slot_max(&Mx[par][3], eb.vmax(pow2(-e21)), lane);
+    PP_WAIT_VMEM();
+    __syncthreads();
+    // ---- stage B2: layer 2 on half 1  ||  epilogue of (Ybar1, half 0); loads: gates X0 -> GT[0]
+    const int e10 = scale_exp(slot_get(&Mx[par][2]) * l1_2), e11 = scale_exp(slot_get(&Mx[par][3]) * l1_2);
+    zero16(acc1);
+    eb.begin(grow1);
+    mma_half(&At[1][32 * LDH2], w2, acc1, l31, lh, [&](int ks) {
+      if (ks < 2) stage_gate_piece(X0, r0, 0, ks);
+      eb.step(ks, acc0, pow2(-(e20 + ew2)), pow2(e10), ok0, crow + 2 * LS, arow0);
+    });
+    __syncthreads();
+    // ---- stage A1: layer 1 on half 0  ||  epilogue of (Ybar1, half 1)
+    zero16(acc0);
+    eb.begin(grow1 + 8 * 128);
+    mma_half(&At[0][0], w1, acc0, l31, lh, [&](int ks) {
+      eb.step(ks, acc1, pow2(-(e21 + ew2)), pow2(e11), ok1, crow + 2 * LS + 32 * 128, arow0 + 32 * LDH2);
+    });
+    PP_WAIT_VMEM();
+    __syncthreads();
+    // ---- stage B1: layer 1 on half 1  ||  epilogue of (Ybar0, half 0) into the fp32 view; then that of half 1
+    HalfEpilogueB<false> ef;
+    zero16(acc1);
+    ef.begin(grow0);
+    mma_half(&At[0][32 * LDH2], w1, acc1, l31, lh, [&](int ks) {
+      ef.step(ks, acc0, pow2(-(e10 + ew1)), 1.f, false, nullptr, reinterpret_cast<_Float16*>(frow1));
+    });
+    ef.begin(grow0 + 8 * 128);
+    ef.all(acc1, pow2(-(e11 + ew1)), 1.f, false, nullptr, reinterpret_cast<_Float16*>(frow1 + 32 * LDA));
+    __syncthreads();
+    // ---- layer 0: W0bar[j][i] += Ybar0[4s][j] p_i + Ybar0[4s+1+i][j], b0bar[j] += Ybar0[4s][j]  (thread = feature j0)
+    const float* As1 = reinterpret_cast<const float*>(At[1]);
+    {
+      const float* __restrict__ yb = &As1[(4 * h0 * 8) * LDA + j0];
+      const float* ps = &Ps[par][h0 * 24];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float y0 = yb[(4 * q) * LDA], y1 = yb[(4 * q + 1) * LDA], y2 = yb[(4 * q + 2) * LDA], y3 = yb[(4 * q + 3) * LDA];
+        wacc0[0] += y0 * ps[q * 3] + y1;
+        wacc0[1] += y0 * ps[q * 3 + 1] + y2;
+        wacc0[2] += y0 * ps[q * 3 + 2] + y3;
+        bacc0 += y0;
+      }
+    }
+    // pts_grad[s][i] = sum_j Ybar0[4s][j] W0[j][i] on v_mfma_f32_4x4x1 (lane = row, K slice per wavefront)
+    {
+      const float* xr = &As1[lane * LDA + 32 * wid];
+      const float* wr = &W0s[(lane & 3) * LDA + 32 * wid];
+      float4 xv[8], wv[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        xv[g] = *reinterpret_cast<const float4*>(xr + 4 * g);
+        wv[g] = *reinterpret_cast<const float4*>(wr + 4 * g);
+      }
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].x, wv[g].x, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].y, wv[g].y, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].z, wv[g].z, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].w, wv[g].w, d1, 0, 0, 0);
+      }
+      Red[wid * 64 + lane] = d0[0] + d1[0];       // register 0 = primal row of sample lane>>2, output lane&3
+    }
+    // ---- the next tile's output-layer backward: W4bar sums, Ybar3 image into tile 0 (last read by stage B1's MFMAs)
+    if (more) {
+      w4_accumulate(par ^ 1);
+      out_layer_bwd(tnext, par ^ 1);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int s = tid >> 2, i = tid & 3;
+      if (i < 3 && s0 + s < M) {
+        const float v = (Red[tid] + Red[64 + tid]) + (Red[128 + tid] + Red[192 + tid]);
+        atomicAdd(&pts_grad[(s0 + s) * 3 + i], v);
+      }
+    }
+  }
+
+  // ---- flush the thin-layer weight gradients (one atomic per entry and work-group)
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(At[0]);
+  if (h0 == 1) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) red[o * 128 + j0] = wacc4[o];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) red[(4 + i) * 128 + j0] = wacc0[i];
+    red[7 * 128 + j0] = bacc0;
+    if (j0 < 4) red[8 * 128 + j0] = bacc4;
+  }
+  __syncthreads();
+  if (h0 == 0) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) atomicAdd(&params_grad[WPF_W4 + o * 128 + j0], (wacc4[o] + red[o * 128 + j0]) * out_range);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) atomicAdd(&params_grad[WPF_W0 + j0 * 3 + i], wacc0[i] + red[(4 + i) * 128 + j0]);
+    atomicAdd(&params_grad[WPF_B0 + j0], bacc0 + red[7 * 128 + j0]);
+    if (j0 < 4) atomicAdd(&params_grad[WPF_B4 + j0], (bacc4 + red[8 * 128 + j0]) * out_range);
+  }
+}
+
+int pp_launch_warp_fused_bwd_s(const float* params, const float* pts, const float* acts, const float* out_grad,
+                               const int32_t* count, int capacity, float out_range, float* ybar, float* params_grad,
+                               float* pts_grad, hipStream_t st) {
+  const int ntiles = pp_div_up(capacity, 16);
+  const int grid = ntiles < PP_FUSED_WGS ? ntiles : PP_FUSED_WGS;
+  hipLaunchKernelGGL(k_warp_fused_bwd_s, dim3(grid), dim3(256), 0, st, params, pts, acts, out_grad, count, capacity, out_range,
+                     ybar, params_grad, pts_grad);
+  return 0;
+}
