@@ -699,14 +699,20 @@ __global__ __launch_bounds__(256) void k_wgrad_chain(WgradLayer LA, WgradLayer L
   // Six steps per iteration keep the buffer assignment static: A0 B1 C0 | A1 B0 C1.  The unit of work is a PAIR of
   // adjacent tiles, so only the very last pair can contain an empty tile (rows clamped, Y zeroed by fix_tail);
   // straight-line control flow keeps the 192 accumulator registers pinned across the hand-scheduled blocks.
-  // optional bias gradients: thread = (feature tid & 127, row half tid >> 7); rows past R are zero in LDS (fix_tail)
+  // optional bias gradients: thread = (feature tid & 127, row half tid >> 7); rows past R are zero in LDS (fix_tail).  The eight
+  // LDS reads are issued BEFORE the hand-scheduled MFMA block and summed after it (colsum_take: the empty asm is their first
+  // use), so their latency hides behind the block instead of in front of it.
   float bA = 0.f, bB = 0.f, bC = 0.f;
-  auto colsum = [&](const float* Ybuf) {
+  float cs[8];
+  auto colsum_issue = [&](const float* Ybuf) {
     const float* p = Ybuf + (tid >> 7) * 32 * 128 + (tid & 127);
-    float sum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 32; r += 4) sum += p[r * 128];
-    return sum;
+    for (int r = 0; r < 8; ++r) cs[r] = p[r * 4 * 128];
+  };
+  auto colsum_take = [&]() {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) asm volatile("" : "+v"(cs[r]));
+    return ((cs[0] + cs[1]) + (cs[2] + cs[3])) + ((cs[4] + cs[5]) + (cs[6] + cs[7]));
   };
   const int npairs = (ntiles + 1) >> 1;
   // Tiles are walked from the END of the row range: the backward-data kernel that just ran wrote Ybar front to back, so its
@@ -718,28 +724,34 @@ __global__ __launch_bounds__(256) void k_wgrad_chain(WgradLayer LA, WgradLayer L
     const int t2 = pair + gridDim.x;
     PP_WAIT_VMEM(); __syncthreads();
     fix_tail(r0, Yb0);
-    if (LA.bbar) bA += colsum(Yb0);
+    if (LA.bbar) colsum_issue(Yb0);
     wgrad_step<128, 128>(true, LB, r0, R, Yb1, Xb1, Yb0, Xb0, accA, wid, lane);
+    if (LA.bbar) bA += colsum_take();
     PP_WAIT_VMEM(); __syncthreads();
     fix_tail(r0, Yb1);
-    if (LB.bbar) bB += colsum(Yb1);
+    if (LB.bbar) colsum_issue(Yb1);
     wgrad_step<KXC, 128>(true, LC, r0, R, Yb0, Xb0, Yb1, Xb1, accB, wid, lane);
+    if (LB.bbar) bB += colsum_take();
     PP_WAIT_VMEM(); __syncthreads();
     fix_tail(r0, Yb0);
-    if (LC.bbar) bC += colsum(Yb0);
+    if (LC.bbar) colsum_issue(Yb0);
     wgrad_step<128, KXC>(true, LA, r1, R, Yb1, Xb1, Yb0, Xb0, accC, wid, lane);
+    if (LC.bbar) bC += colsum_take();
     PP_WAIT_VMEM(); __syncthreads();
     fix_tail(r1, Yb1);
-    if (LA.bbar) bA += colsum(Yb1);
+    if (LA.bbar) colsum_issue(Yb1);
     wgrad_step<128, 128>(true, LB, r1, R, Yb0, Xb0, Yb1, Xb1, accA, wid, lane);
+    if (LA.bbar) bA += colsum_take();
     PP_WAIT_VMEM(); __syncthreads();
     fix_tail(r1, Yb0);
-    if (LB.bbar) bB += colsum(Yb0);
+    if (LB.bbar) colsum_issue(Yb0);
     wgrad_step<KXC, 128>(true, LC, r1, R, Yb1, Xb1, Yb0, Xb0, accB, wid, lane);
+    if (LB.bbar) bB += colsum_take();
     PP_WAIT_VMEM(); __syncthreads();
     fix_tail(r1, Yb1);
-    if (LC.bbar) bC += colsum(Yb1);
+    if (LC.bbar) colsum_issue(Yb1);
     wgrad_step<128, KXC>(t2 < npairs, LA, (npairs - 1 - t2) * 2 * TILE_ROWS, R, Yb0, Xb0, Yb1, Xb1, accC, wid, lane);
+    if (LC.bbar) bC += colsum_take();
   }
   wgrad_flush<128>(LA.Wbar, accA, wr, wc, l31, lh);
   wgrad_flush<128>(LB.Wbar, accB, wr, wc, l31, lh);

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+LAST = None                 # (first, last) photometric loss of the most recent run, for tools/dbg/conv_loop.py
 
 
 def _render_views(eng, V, H, W, step):
@@ -80,8 +81,12 @@ def test_student_converges_to_teacher_images_and_poses():
             (first if s < 3 else last).append(student.losses()['img_render'])
     torch.cuda.synchronize()
     l0, l1 = float(np.median(first)), float(np.median(last))         # per-step batches differ: medians
-    # typical: 0.03 -> 0.002..0.008 (unordered float atomics make the trajectory run-to-run different)
-    assert np.isfinite(l1) and l1 < 0.5 * l0, f'photometric loss {l0:.4e} -> {l1:.4e}'
+    global LAST
+    LAST = (l0, l1)
+    # typical: 0.030 -> 0.0015..0.0045 (unordered float atomics make the trajectory run-to-run different); about 2 % of the runs -
+    # with the fp32 and with the split-precision MLP kernels alike, tools/dbg/conv_loop.py: 2/80 and 1/80 - settle in a second
+    # basin at 0.0150..0.0160
+    assert np.isfinite(l1) and l1 < 0.6 * l0, f'photometric loss {l0:.4e} -> {l1:.4e}'
     # view 0 is never refined (recon_scene.py:68); the other two do move (their optimum is not unique: the deformation
     # network can absorb a rigid motion, so no claim about the direction is made here)
     se3 = student.se3.detach().cpu().numpy()
