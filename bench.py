@@ -10,8 +10,9 @@ child, before anything touches the GPU), relays rank 0's JSON line and exits wit
 own `torch.distributed.run` launch (RANK set) runs the ranks directly.
 
 Prints ONE JSON line on rank 0 (driver contract).  Objects besides the contract's scalar fields:
-  roofline          the longest kernel of the timed step, priced live with HIP events inside the timed region (the
-                    warp-MLP data-gradient kernel on fp32 MFMA, or the fused TV + Adam grid pass on HBM)
+  roofline          the longest kernel of the timed step, priced live with HIP events inside the timed region: the fused
+                    TV + Adam grid pass (HBM), the warp MLP's data-gradient kernel or its weight-gradient kernel (MFMA; a
+                    split-precision kernel is priced against the fp16 pipe with the 3 x FLOPs it issues)
   roofline_grid     the fused TV + Adam pass over the dense k0 grid against the HBM peak (always reported)
   roofline_mlp      both MLP chains as a whole (6 kernels) against the fp32 MFMA peak; `kernels` lists each of them
   dual_branch       BASELINE config 2 as the reference runs it: object step + scene branch (bg_nerf) sharing the poses;
@@ -516,6 +517,7 @@ def main():
     ops.grid_tv_adam_step = timed('k_grid_tv_adam', ops.grid_tv_adam_step)                   # dense pass (ZeRO-1 slabs)
     ops.grid_tv_adam_step_sparse = timed('k_grid_tv_adam', ops.grid_tv_adam_step_sparse)     # same kernel, touched-voxel map
     ops.warp_bwd_data = timed('k_warp_fused_bwd', ops.warp_bwd_data)
+    ops.warp_bwd_weights = timed('k_wgrad_chain<128> (warp)', ops.warp_bwd_weights)
     ops.warp_bwd = staged_warp_bwd
 
     gs = 10
@@ -534,7 +536,7 @@ def main():
         dt = float(t.item())
     M = int(eng.ws.count.item())
     mean_ms = lambda name: float(np.mean([a.elapsed_time(b) for a, b in events[name]])) if events.get(name) else float('nan')
-    grid_ms, warp_bwd_ms = mean_ms('k_grid_tv_adam'), mean_ms('k_warp_fused_bwd')
+    grid_ms, warp_bwd_ms, wgrad_ms = mean_ms('k_grid_tv_adam'), mean_ms('k_warp_fused_bwd'), mean_ms('k_wgrad_chain<128> (warp)')
     exchange_rows = None if dctx is None else dctx.rows
 
     # post-pass (untimed): every MLP kernel on its own event pair -> kernel table and the MLP-chain roofline
@@ -543,6 +545,7 @@ def main():
         setattr(ops, n, originals[n])
     ops.warp_fwd = timed('k_warp_fused_fwd', originals['warp_fwd'])
     ops.rgbnet_fwd = timed('k_rgb_fused_fwd', originals['rgbnet_fwd'])
+    ops.warp_bwd_data = timed('k_warp_fused_bwd', originals['warp_bwd_data'])
     ops.warp_bwd_weights = timed('k_wgrad_chain<128> (warp)', originals['warp_bwd_weights'])
     ops.rgbnet_bwd_data = timed('k_rgb_fused_bwd', originals['rgbnet_bwd_data'])
     ops.rgbnet_bwd_weights = timed('k_wgrad_chain<64> (rgbnet)', originals['rgbnet_bwd_weights'])
@@ -557,10 +560,22 @@ def main():
     flops = {'k_warp_fused_fwd': 3 * 4 * hidden, 'k_warp_fused_bwd': 3 * 4 * hidden, 'k_wgrad_chain<128> (warp)': 3 * 4 * hidden,
              'k_rgb_fused_fwd': 2 * (64 * 128 + 2 * 128 * 128), 'k_rgb_fused_bwd': 2 * (64 * 128 + 2 * 128 * 128),
              'k_wgrad_chain<64> (rgbnet)': 2 * (64 * 128 + 2 * 128 * 128)}          # MFMA-shaped FLOP per sample
-    kernels = {}
-    for name, fl in flops.items():
-        ms = mean_ms(name)
-        kernels[name] = {'ms': ms, 'tflops': fl * Mx / (ms * 1e-3) / 1e12, 'frac_of_fp32_mfma_peak': fl * Mx / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF}
+    # which kernels run their 128 x 128 products as three fp16 MFMA products per fp32 product (option mlp_split, pp_mlp_split.hip):
+    # those are priced against the fp16 pipe with the FLOPs they actually issue (3 x), the others against the fp32 instructions
+    from poseprobe_amd import _lib
+    split_bits = _lib.get_option('mlp_split') if _lib.get_option('mlp_fused') else 0
+    split_of = {'k_warp_fused_fwd': split_bits & 1, 'k_warp_fused_bwd': split_bits & 2, 'k_rgb_fused_fwd': split_bits & 4,
+                'k_rgb_fused_bwd': split_bits & 8}
+
+    def price(name, fl, ms, samples):
+        tf = fl * samples / (ms * 1e-3) / 1e12
+        if split_of.get(name):
+            return {'ms': ms, 'algorithmic_tflops': tf, 'pipe': 'fp16 MFMA 32x32x16, 3 products per fp32 product', 'issued_tflops': 3 * tf,
+                    'peak': FP16_MFMA_PEAK_TF, 'frac': 3 * tf / FP16_MFMA_PEAK_TF}
+        return {'ms': ms, 'algorithmic_tflops': tf, 'pipe': 'fp32 MFMA 32x32x2', 'issued_tflops': tf, 'peak': FP32_MFMA_PEAK_TF,
+                'frac': tf / FP32_MFMA_PEAK_TF}
+
+    kernels = {name: price(name, fl, mean_ms(name), Mx) for name, fl in flops.items()}
     mlp_ms = float(np.sum([k['ms'] for k in kernels.values()]))
     flop_per_sample = sum(flops.values())
     mlp_tflops = flop_per_sample * Mx / (mlp_ms * 1e-3) / 1e12
@@ -579,13 +594,18 @@ def main():
                      'achieved': grid_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': grid_gbs / HBM_PEAK_GBS,
                      'traffic': pmc_traffic(G, (xe - xb) * Y * Z, marked < 1.0), 'traffic_source': 'committed rocprofv3 PMC pass (profiles/), not this run',
                      'ms_per_launch': grid_ms, 'algorithmic_bytes_per_launch': grid_bytes, 'grad_voxels_marked': marked}
-    wb_tf = flops['k_warp_fused_bwd'] * M / (warp_bwd_ms * 1e-3) / 1e12
-    roofline_warp_bwd = {'bound': 'mfma', 'kernel': 'k_warp_fused_bwd (warp MLP data-gradient chain: 3 hidden layers x 4 rows per sample, fp32 MFMA 32x32x2; '
-                                                    'thin layers + bias gradients in the same kernel)',
-                         'achieved': wb_tf, 'peak': FP32_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': wb_tf / FP32_MFMA_PEAK_TF, 'traffic': None,
-                         'ms_per_launch': warp_bwd_ms, 'algorithmic_flops_per_launch': flops['k_warp_fused_bwd'] * M,
-                         'flop_per_sample': flops['k_warp_fused_bwd'], 'samples': M}
-    dominant = roofline_warp_bwd if warp_bwd_ms >= grid_ms else roofline_grid
+    def mfma_roofline(name, what, ms):
+        pr = price(name, flops[name], ms, M)
+        return {'bound': 'mfma', 'kernel': f'{name} ({what}; {pr["pipe"]})', 'achieved': pr['issued_tflops'], 'peak': pr['peak'],
+                'unit': 'TFLOP/s', 'frac': pr['frac'], 'traffic': None, 'ms_per_launch': ms,
+                'algorithmic_flops_per_launch': flops[name] * M, 'flop_per_sample': flops[name], 'samples': M,
+                'algorithmic_tflops': pr['algorithmic_tflops']}
+
+    # the longest kernel of the timed step among the three live-timed candidates
+    candidates = [(grid_ms, roofline_grid),
+                  (warp_bwd_ms, mfma_roofline('k_warp_fused_bwd', 'warp MLP data-gradient chain: 3 hidden layers x 4 rows per sample, thin layers in the same kernel', warp_bwd_ms)),
+                  (wgrad_ms, mfma_roofline('k_wgrad_chain<128> (warp)', 'weight gradients of the three hidden warp layers in one persistent kernel', wgrad_ms))]
+    dominant = max((c for c in candidates if np.isfinite(c[0])), key=lambda c: c[0])[1]
 
     dual = None
     if world == 1 and not args.no_dual:
@@ -607,7 +627,9 @@ def main():
                                    f'in HBM (the reference draws randperm inside the step)', 'grid': G, 'n_rand_per_gpu': N,
                        'samples_in_bbox_last_step': M, 'parallelism': par},
             'roofline': dominant, 'roofline_grid': roofline_grid,
-            'roofline_mlp': {'bound': 'mfma', 'kernel': 'warp + rgbnet MLP chains (6 layer-fused kernels: fwd / bwd-data / weight-gradient, fp32 MFMA 32x32x2)',
+            'roofline_mlp': {'bound': 'mfma', 'kernel': 'warp + rgbnet MLP chains (6 layer-fused kernels: fwd / bwd-data / weight-gradient); ALGORITHMIC '
+                                                        'fp32 FLOP/s of the six kernels together over the fp32 MFMA peak - the kernels listed with an fp16 pipe '
+                                                        'issue three times their algorithmic FLOPs on the fp16 instructions, see `kernels`',
                              'achieved': mlp_tflops, 'peak': FP32_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': mlp_tflops / FP32_MFMA_PEAK_TF,
                              'traffic': None, 'ms_per_step': mlp_ms, 'flop_per_sample': flop_per_sample, 'kernels': kernels,
                              'measured': f'untimed post-pass of {extra} steps, one HIP event pair per kernel'},
