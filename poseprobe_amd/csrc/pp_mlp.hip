@@ -355,7 +355,8 @@ extern "C" int pp_mlp_fwd(const float* params, const float* feat, int32_t in_ld,
   PP_REQUIRE(capacity > 0 && in_ld % 32 == 0 && in_ld <= 128 && n_gemm >= 1 && n_gemm <= 8, "bad sizes");
   hipStream_t st = pp_stream(stream);
   if (in_ld == 64 && n_gemm == 3 && mlp_fused_enabled()) {       // the Voxurf rgbnet shape: layer-fused kernel
-    pp_launch_rgb_fused_fwd(params, feat, count, capacity, logit_add, logit_add_ld, acts, out, st);
+    if (pp_opt(PP_OPT_MLP_SPLIT) & 4) pp_launch_rgb_fused_fwd_s(params, feat, count, capacity, logit_add, logit_add_ld, acts, out, st);
+    else pp_launch_rgb_fused_fwd(params, feat, count, capacity, logit_add, logit_add_ld, acts, out, st);
     PP_CHECK_LAUNCH();
     return PP_OK;
   }

@@ -49,6 +49,8 @@ int pp_launch_wgrad_chain(const float* YA, const float* XA, float* WA, const flo
 
 int pp_launch_rgb_fused_fwd(const float* params, const float* feat, const int32_t* count, int capacity,
                             const float* logit_add, int add_ld, float* acts, float* rgb, hipStream_t st);
+int pp_launch_rgb_fused_fwd_s(const float* params, const float* feat, const int32_t* count, int capacity,
+                              const float* logit_add, int add_ld, float* acts, float* rgb, hipStream_t st);
 int pp_launch_rgb_fused_bwd(const float* params, const float* acts, const float* rgb, const float* rgb_grad,
                             const int32_t* count, int capacity, float* ybar, float* params_grad, float* feat_grad,
                             float* logit_grad, int lg_ld, hipStream_t st);

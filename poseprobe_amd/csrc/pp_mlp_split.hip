@@ -128,18 +128,18 @@ __device__ __forceinline__ int load_w_rows_split(SplitW& w, float& l1, const flo
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 // acc[reg] += sum_k W[feature(reg)][k] X[row l31][k]  for 32 rows of a split tile (`rows` = hi plane of the first of them, lo
 // plane PLANE halfs behind); hook(ks), ks = 0..7, is called after the three MFMAs of every operand group - work placed there is
-// issued in the shadow of the matrix pipe
-template <class Hook = NoHook>
+// issued in the shadow of the matrix pipe (KS operand groups of 16, row stride LD halfs, lo plane PL halfs behind the hi plane)
+template <int KS = 8, int LD = LDH2, int PL = PLANE, class Hook = NoHook>
 __device__ __forceinline__ void mma_half(const _Float16* __restrict__ rows, const SplitW& w, f32x16& acc, int l31, int lh,
                                          Hook hook = Hook()) {
-  const _Float16* p = rows + l31 * LDH2 + 8 * lh;
-  pp_half8 h = *reinterpret_cast<const pp_half8*>(p), l = *reinterpret_cast<const pp_half8*>(p + PLANE);
+  const _Float16* p = rows + l31 * LD + 8 * lh;
+  pp_half8 h = *reinterpret_cast<const pp_half8*>(p), l = *reinterpret_cast<const pp_half8*>(p + PL);
 #pragma unroll
-  for (int ks = 0; ks < (MS_DBG == 1 ? 0 : 8); ++ks) {
+  for (int ks = 0; ks < (MS_DBG == 1 ? 0 : KS); ++ks) {
     pp_half8 nh = h, nl = l;
-    if (ks + 1 < 8) {
+    if (ks + 1 < KS) {
       nh = *reinterpret_cast<const pp_half8*>(p + 16 * (ks + 1));
-      nl = *reinterpret_cast<const pp_half8*>(p + 16 * (ks + 1) + PLANE);
+      nl = *reinterpret_cast<const pp_half8*>(p + 16 * (ks + 1) + PL);
     }
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h[ks], l, acc, 0, 0, 0);      // small terms first
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.l[ks], h, acc, 0, 0, 0);
@@ -893,5 +893,207 @@ int pp_launch_warp_fused_bwd_s(const float* params, const float* pts, const floa
   const int grid = ntiles < PP_FUSED_WGS ? ntiles : PP_FUSED_WGS;
   hipLaunchKernelGGL(k_warp_fused_bwd_s, dim3(grid), dim3(256), 0, st, params, pts, acts, out_grad, count, capacity, out_range,
                      ybar, params_grad, pts_grad);
+  return 0;
+}
+
+// ================================================================================================ rgbnet (64 -> 128 x3 -> 3)
+// Same contract as k_rgb_fused_fwd (pp_mlp_fused.hip): feat[M][64] -> rgb[M][3] = sigmoid(MLP(feat) (+ logit_add)); hidden
+// activations H0..H2 ([cap][128] fp32 each) kept for backward.  One row per sample, so the gate is a plain ReLU (COLS == 1).
+// The input tile arrives by LDS-direct loads as fp32 and is split by the threads that fetched it: four threads per row, the row's
+// own power of two as scale (rows are the N index of the product, so the scale may differ per row; the epilogue's factor is then
+// per lane).
+namespace {
+
+#define FLD 72                          // halfs per row of the split feature tile (144 B: conflict-free ds_read_b128 fragments)
+#define FPL (TILE_ROWS * FLD)
+
+// forward weights of feature n of the 64-wide input layer: k = 16 ks + 8 lh + j, ks < 4 (the upper half of `w` stays unused)
+__device__ __forceinline__ int load_w0_rows_split(SplitW& w, float& l1, const float* __restrict__ W, int n, int lh, float* red, int tid) {
+  float4 v[8];
+  float mx = 0.f, sum = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    v[2 * ks] = *reinterpret_cast<const float4*>(W + (size_t)n * 64 + 16 * ks + 8 * lh);
+    v[2 * ks + 1] = *reinterpret_cast<const float4*>(W + (size_t)n * 64 + 16 * ks + 8 * lh + 4);
+    mx = fmaxf(mx, fmaxf(amax4(v[2 * ks]), amax4(v[2 * ks + 1])));
+    sum += asum4(v[2 * ks]) + asum4(v[2 * ks + 1]);
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  const int e = scale_exp(block_max(mx, red, tid));
+  const float s = pow2(e);
+  l1 = block_max(sum, red, tid) * 1.0001f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) split8(v[2 * ks], v[2 * ks + 1], s, w.h[ks], w.l[ks]);
+#pragma unroll
+  for (int ks = 4; ks < 8; ++ks) { w.h[ks] = w.h[0]; w.l[ks] = w.l[0]; }
+  return e;
+}
+
+// LDS-direct load of a [64][64] fp32 tile into an unpadded buffer whose 16-byte slots are XOR-swizzled (pp_mlp_fused.hip)
+__device__ __forceinline__ void stage_feat_tile_s(const float* __restrict__ feat, int r0, int R, float* Fs, int wid, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl = 16 * wid + 4 * i + (lane >> 4);            // four rows per instruction
+    const int c4 = (lane & 15) ^ (rl & 15);
+    const int row = min(r0 + rl, R - 1);
+    __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(feat + (size_t)row * 64 + c4 * 4), PP_LDS_PTR(Fs + (16 * wid + 4 * i) * 64), 16, 0, 0);
+  }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_rgb_fused_fwd_s(const float* __restrict__ params, const float* __restrict__ feat,
+                                                         const int32_t* __restrict__ count, int capacity,
+                                                         const float* __restrict__ logit_add, int add_ld,
+                                                         float* __restrict__ acts, float* __restrict__ rgb) {
+  __shared__ __attribute__((aligned(16))) _Float16 At[2][2 * PLANE];      // tile 0 doubles as the fp32 [64][LDA] view (H2)
+  __shared__ __attribute__((aligned(16))) float Fs[2][TILE_ROWS * 64];    // fp32 feature tiles (current / next), swizzled slots
+  __shared__ __attribute__((aligned(16))) _Float16 Fh[2 * FPL];           // split image of the current feature tile
+  __shared__ __attribute__((aligned(16))) float W3s[4 * LDA];
+  __shared__ __attribute__((aligned(16))) float Red[4 * 64 * 4];
+  __shared__ __attribute__((aligned(16))) float Bs[3][128];
+  __shared__ int Er[TILE_ROWS];                                            // scale exponent of every row of the feature tile
+  __shared__ unsigned Mx[2][8];      // per parity: max |feat| (halves 0, 1), |H0| (0, 1), |H1| (0, 1)
+  __shared__ float red4[4];
+  const int R = min(count[0], capacity);
+  const int ntiles = (R + TILE_ROWS - 1) / TILE_ROWS;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int col = wid * 32 + l31;
+  const int fb = wid * 32 + 4 * lh;
+  const size_t LS = (size_t)capacity * 128;
+
+  SplitW w0, w1, w2;
+  float l1_0, l1_1, l1_2;
+  const int ew0 = load_w0_rows_split(w0, l1_0, params + RGF_W0, col, lh, red4, tid);
+  const int ew1 = load_w_rows_split(w1, l1_1, params + RGF_W1, col, lh, red4, tid);
+  const int ew2 = load_w_rows_split(w2, l1_2, params + RGF_W2, col, lh, red4, tid);
+  if (tid < 128) { Bs[0][tid] = params[RGF_B0 + tid]; Bs[1][tid] = params[RGF_B1 + tid]; Bs[2][tid] = params[RGF_B2 + tid]; }
+  const float b0mx = block_max(fabsf(params[RGF_B0 + col]), red4, tid), b1mx = block_max(fabsf(params[RGF_B1 + col]), red4, tid);
+  for (int i = tid; i < 512; i += 256) {
+    const int r = i >> 7, j = i & 127;
+    W3s[r * LDA + j] = (r < 3) ? params[RGF_W3 + r * 128 + j] : 0.f;
+  }
+  const float b3 = ((tid & 3) < 3) ? params[RGF_B3 + (tid & 3)] : 0.f;
+  if (tid < 16) Mx[tid >> 3][tid & 7] = 0u;
+  stage_feat_tile_s(feat, blockIdx.x * TILE_ROWS, R, Fs[0], wid, lane);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+
+  int par = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
+    const int r0 = tile * TILE_ROWS;
+    const int tnext = tile + gridDim.x;
+    const bool ok0 = r0 + l31 < R, ok1 = r0 + 32 + l31 < R;
+    float* __restrict__ crow = acts + (size_t)(r0 + l31) * 128 + fb;
+    _Float16* const arow0 = &At[0][l31 * LDH2 + fb];
+    _Float16* const arow1 = &At[1][l31 * LDH2 + fb];
+    float* const frow0 = reinterpret_cast<float*>(At[0]) + l31 * LDA + fb;      // fp32 view of tile 0
+    // ---- split the feature tile: thread = (row tid >> 2, 16 columns); the rows a wavefront converts are the rows it loaded
+    PP_WAIT_VMEM();
+    {
+      const int row = tid >> 2, qd = tid & 3;
+      float4 f[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const float4*>(&Fs[par][row * 64 + (((4 * qd + i) ^ (row & 15)) << 2)]);
+      float mx = fmaxf(fmaxf(amax4(f[0]), amax4(f[1])), fmaxf(amax4(f[2]), amax4(f[3])));
+      if (r0 + row >= R) { mx = 0.f; f[0] = f[1] = f[2] = f[3] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      mx = fmaxf(mx, dpp_f<0xB1>(mx));
+      mx = fmaxf(mx, dpp_f<0x4E>(mx));                                  // the row's maximum in all four of its lanes
+      const int er = scale_exp(mx);
+      const float sr = pow2(er);
+      pp_half8 h0, l0, h1, l1;
+      split8(f[0], f[1], sr, h0, l0);
+      split8(f[2], f[3], sr, h1, l1);
+      _Float16* d = &Fh[row * FLD + 16 * qd];
+      *reinterpret_cast<pp_half8*>(d) = h0; *reinterpret_cast<pp_half8*>(d + 8) = h1;
+      *reinterpret_cast<pp_half8*>(d + FPL) = l0; *reinterpret_cast<pp_half8*>(d + FPL + 8) = l1;
+      if (qd == 0) Er[row] = er;
+      slot_max(&Mx[par][wid >> 1], mx, lane);                           // rows 16 wid .. 16 wid + 15 belong to half wid >> 1
+    }
+    if (tnext < ntiles) stage_feat_tile_s(feat, tnext * TILE_ROWS, R, Fs[par ^ 1], wid, lane);   // lands during this tile
+    __syncthreads();
+    if (tid < 6) Mx[par ^ 1][tid] = 0u;
+    f32x16 acc0, acc1;
+    HalfEpilogue<1, true> ea;
+    // ---- layer 0 (64 -> 128): half 0, then half 1 beside the epilogue of half 0
+    const int e00 = scale_exp(fmaf(slot_get(&Mx[par][0]), l1_0, b0mx)), e01 = scale_exp(fmaf(slot_get(&Mx[par][1]), l1_0, b0mx));
+    const float inv00 = pow2(-(Er[l31] + ew0)), inv01 = pow2(-(Er[32 + l31] + ew0));          // per lane: the row's own scale
+    zero16(acc0);
+    mma_half<4, FLD, FPL>(&Fh[0], w0, acc0, l31, lh);
+    zero16(acc1);
+    ea.begin(&Bs[0][fb]);
+    mma_half<4, FLD, FPL>(&Fh[32 * FLD], w0, acc1, l31, lh, [&](int ks) {
+      ea.step(2 * ks, acc0, inv00, pow2(e00), ok0, crow, arow0);
+      ea.step(2 * ks + 1, acc0, inv00, pow2(e00), ok0, crow, arow0);
+    });
+    slot_max(&Mx[par][2], ea.vmax(pow2(-e00)), lane);
+    __syncthreads();
+    // ---- stage A1: layer 1 on half 0  ||  epilogue of (layer 0, half 1)
+    zero16(acc0);
+    ea.begin(&Bs[0][fb]);
+    mma_half(&At[0][0], w1, acc0, l31, lh, [&](int ks) { ea.step(ks, acc1, inv01, pow2(e01), ok1, crow + 32 * 128, arow0 + 32 * LDH2); });
+    slot_max(&Mx[par][3], ea.vmax(pow2(-e01)), lane);
+    __syncthreads();
+    // ---- stage B1: layer 1 on half 1  ||  epilogue of (layer 1, half 0)
+    const int e10 = scale_exp(fmaf(slot_get(&Mx[par][2]), l1_1, b1mx));
+    zero16(acc1);
+    ea.begin(&Bs[1][fb]);
+    mma_half(&At[0][32 * LDH2], w1, acc1, l31, lh, [&](int ks) { ea.step(ks, acc0, pow2(-(e00 + ew1)), pow2(e10), ok0, crow + LS, arow1); });
+    __syncthreads();
+    // ---- stage A2: layer 2 on half 0  ||  epilogue of (layer 1, half 1)
+    const int e11 = scale_exp(fmaf(slot_get(&Mx[par][3]), l1_1, b1mx));
+    zero16(acc0);
+    ea.begin(&Bs[1][fb]);
+    mma_half(&At[1][0], w2, acc0, l31, lh, [&](int ks) { ea.step(ks, acc1, pow2(-(e01 + ew1)), pow2(e11), ok1, crow + LS + 32 * 128, arow1 + 32 * LDH2); });
+    __syncthreads();
+    // ---- stage B2: layer 2 on half 1  ||  epilogue of (layer 2, half 0) into the fp32 view; then that of half 1
+    HalfEpilogue<1, false> ef;
+    zero16(acc1);
+    ef.begin(&Bs[2][fb]);
+    mma_half(&At[1][32 * LDH2], w2, acc1, l31, lh, [&](int ks) { ef.step(ks, acc0, pow2(-(e10 + ew2)), 1.f, ok0, crow + 2 * LS, reinterpret_cast<_Float16*>(frow0)); });
+    ef.begin(&Bs[2][fb]);
+    ef.all(acc1, pow2(-(e11 + ew2)), 1.f, ok1, crow + 2 * LS + 32 * 128, reinterpret_cast<_Float16*>(frow0 + 32 * LDA));
+    __syncthreads();
+    // ---- output layer (128 -> 3) on v_mfma_f32_4x4x1: lane = row, lane&3 = output, K slice per wavefront
+    {
+      const float* As0 = reinterpret_cast<const float*>(At[0]);
+      const float* xr = &As0[lane * LDA + 32 * wid];
+      const float* wr = &W3s[(lane & 3) * LDA + 32 * wid];
+      float4 xv[8], wv[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        xv[g] = *reinterpret_cast<const float4*>(xr + 4 * g);
+        wv[g] = *reinterpret_cast<const float4*>(wr + 4 * g);
+      }
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].x, wv[g].x, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].y, wv[g].y, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].z, wv[g].z, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[g].w, wv[g].w, d1, 0, 0, 0);
+      }
+      *reinterpret_cast<float4*>(&Red[(wid * 64 + lane) * 4]) = make_float4(d0[0] + d1[0], d0[1] + d1[1], d0[2] + d1[2], d0[3] + d1[3]);
+    }
+    __syncthreads();
+    {
+      const int row = tid >> 2, o = tid & 3;
+      const int idx = ((row >> 2) * 4 + o) * 4 + (row & 3);
+      const float sum = (Red[idx] + Red[256 + idx]) + (Red[512 + idx] + Red[768 + idx]);
+      if (o < 3 && r0 + row < R) {
+        const size_t m = (size_t)(r0 + row);
+        rgb[m * 3 + o] = pp_sigmoid(sum + b3 + (logit_add ? logit_add[m * add_ld + o] : 0.f));
+      }
+    }
+  }
+}
+
+int pp_launch_rgb_fused_fwd_s(const float* params, const float* feat, const int32_t* count, int capacity,
+                              const float* logit_add, int add_ld, float* acts, float* rgb, hipStream_t st) {
+  const int ntiles = pp_div_up(capacity, TILE_ROWS);
+  const int grid = ntiles < PP_FUSED_WGS ? ntiles : PP_FUSED_WGS;
+  hipLaunchKernelGGL(k_rgb_fused_fwd_s, dim3(grid), dim3(256), 0, st, params, feat, count, capacity, logit_add, add_ld, acts, rgb);
   return 0;
 }

@@ -37,3 +37,26 @@ for k in a:
     if k == 'out':
         bad = (d > 1e-4).any(1).nonzero().flatten()
         print('   bad samples', len(bad), bad[:20].tolist())
+
+# ---- rgbnet
+rgb_p = torch.zeros(41731 + 60, device=dev); rgb_p[:41731] = rnd(41731, scale=0.09)
+feat = rnd(cap, 64); feat[:, 57:] = 0
+g_rgb = rnd(cap, 3)
+def run_rgb(mode):
+    _lib.set_option('mlp_split', mode)
+    racts = torch.zeros(3 * cap * 128, device=dev); rgb = torch.zeros(cap, 3, device=dev)
+    ops.rgbnet_fwd(rgb_p, feat, count, cap, racts, rgb)
+    rscr = torch.zeros(3 * cap * 128 + 49152, device=dev)
+    rgrad = torch.zeros_like(rgb_p); fgrad = torch.zeros(cap, 64, device=dev)
+    ops.rgbnet_bwd(rgb_p, feat, racts, rgb, g_rgb, count, cap, rscr, rgrad, fgrad)
+    torch.cuda.synchronize()
+    return dict(acts=racts.view(3, cap, 128)[:, :M].clone(), rgb=rgb[:M].clone(), ybar=rscr[:3 * cap * 128].view(3, cap, 128)[:, :M].clone(),
+                wgrad=rgrad.clone(), fgrad=fgrad[:M].clone())
+a, b = run_rgb(0), run_rgb(bits)
+for k in a:
+    d = (a[k] - b[k]).abs()
+    print(f'rgb {k:6s} max|diff| {float(d.max()):.3e}  max|ref| {float(a[k].abs().max()):.3e}  nan {int(torch.isnan(b[k]).sum())}')
+    if k in ('acts', 'ybar'):
+        for l in range(3):
+            bad = d[l] > 1e-4 * float(a[k][l].abs().max())
+            print(f'   layer {l}: max {float(d[l].max()):.3e}, bad elements {int(bad.sum())} in rows {bad.any(1).nonzero().flatten()[:8].tolist()}')
