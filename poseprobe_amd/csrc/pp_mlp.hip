@@ -384,12 +384,16 @@ extern "C" int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld,
   PP_REQUIRE(capacity > 0 && in_ld % 32 == 0 && in_ld <= 128 && n_gemm >= 1 && n_gemm <= 8, "bad sizes");
   hipStream_t st = pp_stream(stream);
   if (in_ld == 64 && n_gemm == 3 && feat_grad && mlp_fused_enabled()) {
-    pp_launch_rgb_fused_bwd(params, acts, out, out_grad, count, capacity, scratch, params_grad, feat_grad, logit_add_grad,
-                            logit_add_ld, st);
+    const bool sb = (pp_opt(PP_OPT_MLP_SPLIT) & 8) != 0;   // split-precision data-gradient kernel: b0..b2 come from the weight-gradient kernel
+    if (sb) pp_launch_rgb_fused_bwd_s(params, acts, out, out_grad, count, capacity, scratch, params_grad, feat_grad, logit_add_grad,
+                                      logit_add_ld, st);
+    else pp_launch_rgb_fused_bwd(params, acts, out, out_grad, count, capacity, scratch, params_grad, feat_grad, logit_add_grad,
+                                 logit_add_ld, st);
     const size_t FLS = (size_t)capacity * 128;
     hipStream_t ws = deferred_fork(ctx, st);
     pp_launch_wgrad_chain(scratch, acts + FLS, params_grad + RGF_W2, scratch + FLS, acts, params_grad + RGF_W1,
-                          scratch + 2 * FLS, feat, params_grad + RGF_W0, 64, count, 1, capacity, ws);
+                          scratch + 2 * FLS, feat, params_grad + RGF_W0, 64, count, 1, capacity, ws,
+                          sb ? params_grad + RGF_B2 : nullptr, sb ? params_grad + RGF_B1 : nullptr, sb ? params_grad + RGF_B0 : nullptr);
     deferred_forked(ctx, ws, st);
     PP_CHECK_LAUNCH();
     return PP_OK;
@@ -568,8 +572,12 @@ extern "C" int pp_rgbnet_bwd_data(const float* params, const float* acts, const 
   PP_REQUIRE(params && acts && rgb && rgb_grad && count && scratch && params_grad && feat_grad, "null pointer");
   PP_REQUIRE(capacity > 0, "capacity<=0");
   if (!mlp_fused_enabled()) { pp_set_error("pp_rgbnet_bwd_data: option mlp_fused = 0 has no two-stage form"); return PP_ERR_UNSUPPORTED; }
-  pp_launch_rgb_fused_bwd(params, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad, nullptr, 0,
-                          pp_stream(stream));
+  if (pp_opt(PP_OPT_MLP_SPLIT) & 8)
+    pp_launch_rgb_fused_bwd_s(params, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad, nullptr, 0,
+                              pp_stream(stream));
+  else
+    pp_launch_rgb_fused_bwd(params, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad, nullptr, 0,
+                            pp_stream(stream));
   PP_CHECK_LAUNCH();
   return PP_OK;
 }
@@ -580,8 +588,10 @@ extern "C" int pp_rgbnet_bwd_weights(const float* feat, const float* acts, const
   PP_REQUIRE(capacity > 0, "capacity<=0");
   if (!mlp_fused_enabled()) { pp_set_error("pp_rgbnet_bwd_weights: option mlp_fused = 0 has no two-stage form"); return PP_ERR_UNSUPPORTED; }
   const size_t FLS = (size_t)capacity * 128;
+  const bool sb = (pp_opt(PP_OPT_MLP_SPLIT) & 8) != 0;     // see pp_mlp_bwd
   pp_launch_wgrad_chain(scratch, acts + FLS, params_grad + RGF_W2, scratch + FLS, acts, params_grad + RGF_W1,
-                        scratch + 2 * FLS, feat, params_grad + RGF_W0, 64, count, 1, capacity, pp_stream(stream));
+                        scratch + 2 * FLS, feat, params_grad + RGF_W0, 64, count, 1, capacity, pp_stream(stream),
+                        sb ? params_grad + RGF_B2 : nullptr, sb ? params_grad + RGF_B1 : nullptr, sb ? params_grad + RGF_B0 : nullptr);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }

@@ -32,7 +32,8 @@ int pp_launch_warp_fused_bwd_s(const float* params, const float* pts, const floa
                                const int32_t* count, int capacity, float out_range, float* ybar, float* params_grad,
                                float* pts_grad, hipStream_t st);
 // weight gradients of three layers (Y_l^T X_l accumulated into W_l) in one persistent kernel; kxc = width of X of layer C;
-// bA / bB / bC (warp net, rmul == 4 only): also accumulate the bias gradients = column sums of Y over the primal rows
+// bA / bB / bC: also accumulate the bias gradients = column sums of Y over the primal rows (kxc == 128: the warp net's 4-row
+// form, every fourth row) or over all rows (kxc == 64: rgbnet)
 int pp_launch_wgrad_chain(const float* YA, const float* XA, float* WA, const float* YB, const float* XB, float* WB,
                           const float* YC, const float* XC, float* WC, int kxc, const int32_t* count, int rmul, int rcap,
                           hipStream_t st, float* bA = nullptr, float* bB = nullptr, float* bC = nullptr);
@@ -51,6 +52,9 @@ int pp_launch_rgb_fused_fwd(const float* params, const float* feat, const int32_
                             const float* logit_add, int add_ld, float* acts, float* rgb, hipStream_t st);
 int pp_launch_rgb_fused_fwd_s(const float* params, const float* feat, const int32_t* count, int capacity,
                               const float* logit_add, int add_ld, float* acts, float* rgb, hipStream_t st);
+int pp_launch_rgb_fused_bwd_s(const float* params, const float* acts, const float* rgb, const float* rgb_grad,
+                              const int32_t* count, int capacity, float* ybar, float* params_grad, float* feat_grad,
+                              float* logit_grad, int lg_ld, hipStream_t st);
 int pp_launch_rgb_fused_bwd(const float* params, const float* acts, const float* rgb, const float* rgb_grad,
                             const int32_t* count, int capacity, float* ybar, float* params_grad, float* feat_grad,
                             float* logit_grad, int lg_ld, hipStream_t st);

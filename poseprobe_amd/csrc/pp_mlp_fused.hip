@@ -573,7 +573,8 @@ struct WgradLayer {
   const float* Y;      // [R][128]   gradient w.r.t. the layer's pre-activation (already gated)
   const float* X;      // [R][KX]    input activations of the layer
   float* Wbar;         // [128][KX]
-  float* bbar;         // [128] or nullptr: += column sums of Y over every FOURTH row (the primal rows of the warp net's 4-row form);
+  float* bbar;         // [128] or nullptr: += column sums of Y over every FOURTH row (KXC == 128: the primal rows of the warp net's 4-row
+                       // form) or over every row (KXC == 64: rgbnet);
                        // used when the data-gradient kernel leaves the hidden-layer bias gradients to this one (pp_mlp_split.hip)
 };
 
@@ -703,16 +704,24 @@ __global__ __launch_bounds__(256) void k_wgrad_chain(WgradLayer LA, WgradLayer L
   // LDS reads are issued BEFORE the hand-scheduled MFMA block and summed after it (colsum_take: the empty asm is their first
   // use), so their latency hides behind the block instead of in front of it.
   float bA = 0.f, bB = 0.f, bC = 0.f;
-  float cs[8];
+  constexpr int NCS = KXC == 64 ? 32 : 8, CSTEP = KXC == 64 ? 1 : 4;     // rgbnet: every row; warp net: the primal rows
+  float cs[NCS];
   auto colsum_issue = [&](const float* Ybuf) {
     const float* p = Ybuf + (tid >> 7) * 32 * 128 + (tid & 127);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) cs[r] = p[r * 4 * 128];
+    for (int r = 0; r < NCS; ++r) cs[r] = p[r * CSTEP * 128];
   };
   auto colsum_take = [&]() {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) asm volatile("" : "+v"(cs[r]));
-    return ((cs[0] + cs[1]) + (cs[2] + cs[3])) + ((cs[4] + cs[5]) + (cs[6] + cs[7]));
+    for (int r = 0; r < NCS; ++r) asm volatile("" : "+v"(cs[r]));
+    float t[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      t[r] = cs[r];
+#pragma unroll
+      for (int k = 8; k < NCS; k += 8) t[r] += cs[r + k];
+    }
+    return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
   };
   const int npairs = (ntiles + 1) >> 1;
   // Tiles are walked from the END of the row range: the backward-data kernel that just ran wrote Ybar front to back, so its

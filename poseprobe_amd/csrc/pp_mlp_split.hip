@@ -1097,3 +1097,252 @@ int pp_launch_rgb_fused_fwd_s(const float* params, const float* feat, const int3
   hipLaunchKernelGGL(k_rgb_fused_fwd_s, dim3(grid), dim3(256), 0, st, params, feat, count, capacity, logit_add, add_ld, acts, rgb);
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ rgbnet, backward
+// Same contract as k_rgb_fused_bwd: output layer, the two 128 x 128 data-gradient products and the 128 -> 64 product onto the
+// features; Ybar2 / Ybar1 / Ybar0 go to `ybar` ([3][cap][128] fp32) for k_wgrad_chain<64>, which also forms b2bar / b1bar / b0bar
+// when this kernel ran (pp_launch_wgrad_chain, stride-1 column sums); W3bar and b3bar are accumulated here (thread = feature).
+// Gates are per element (the layer input's own activation); the tile of gating activations arrives by LDS-direct loads into ONE
+// buffer (H1, then H0 - a second 32 KB buffer does not fit beside the two images and the next tile's H2), so the two halves of
+// Ybar0 are written out without MFMAs beside them.
+__global__ __launch_bounds__(256) void k_rgb_fused_bwd_s(const float* __restrict__ params, const float* __restrict__ acts,
+                                                         const float* __restrict__ rgb, const float* __restrict__ rgb_grad,
+                                                         const int32_t* __restrict__ count, int capacity,
+                                                         float* __restrict__ ybar, float* __restrict__ params_grad,
+                                                         float* __restrict__ feat_grad, float* __restrict__ logit_grad, int lg_ld) {
+  __shared__ __attribute__((aligned(16))) _Float16 At[2][2 * PLANE];
+  __shared__ __attribute__((aligned(16))) float XS[TILE_ROWS * 128];      // H2 of the NEXT tile
+  __shared__ __attribute__((aligned(16))) float GT[TILE_ROWS * 128];      // gates of the current layer (H1, then H0)
+  __shared__ __attribute__((aligned(16))) float RG[2][2][192];            // [parity][rgb | rgb_grad] of a tile
+  __shared__ __attribute__((aligned(16))) float GL[TILE_ROWS * 4];        // d loss / d logits of the staged tile
+  __shared__ unsigned Mx[2][8];      // per parity: max |Ybar2| (halves 0, 1), |Ybar1| (0, 1), max |d logits| of the tile
+  __shared__ float red4[4];
+  const int R = min(count[0], capacity);
+  const int ntiles = (R + TILE_ROWS - 1) / TILE_ROWS;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int col = wid * 32 + l31;
+  const int fb = wid * 32 + 4 * lh;
+  const size_t LS = (size_t)capacity * 128;
+  const float* __restrict__ H0 = acts;
+  const float* __restrict__ H1 = acts + LS;
+  const float* __restrict__ H2 = acts + 2 * LS;
+
+  SplitW w2, w1, w0;
+  float l1_2, l1_1, l1_dummy;
+  const int ew2 = load_w_cols_split(w2, l1_2, params + RGF_W2, col, lh, red4, tid);
+  const int ew1 = load_w_cols_split(w1, l1_1, params + RGF_W1, col, lh, red4, tid);
+  // last product: feat_grad[64 rows][64] = Ybar0 . W0, wavefront = (row half wid >> 1, feature block wid & 1); A operand =
+  // transposed W0 (k = hidden feature, value W0[k][f]) of input feature f = 32 (wid & 1) + l31
+  const int rb = wid >> 1, fcol = (wid & 1) * 32 + l31;
+  int ew0;
+  {
+    float4 v[16];
+    float mx = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const float* p = params + RGF_W0 + (size_t)(16 * ks + 8 * lh) * 64 + fcol;
+      v[2 * ks] = make_float4(p[0], p[64], p[128], p[192]);
+      v[2 * ks + 1] = make_float4(p[256], p[320], p[384], p[448]);
+      mx = fmaxf(mx, fmaxf(amax4(v[2 * ks]), amax4(v[2 * ks + 1])));
+    }
+    ew0 = scale_exp(block_max(mx, red4, tid));
+    const float s = pow2(ew0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) split8(v[2 * ks], v[2 * ks + 1], s, w0.h[ks], w0.l[ks]);
+    l1_dummy = 0.f;
+  }
+  // output layer backward as a K = 16 product: A = [w3_0 w3_1 w3_2 0 ...] of feature `col` (lanes lh = 0), B = d loss / d logits
+  const float w3a = params[RGF_W3 + col], w3b = params[RGF_W3 + 128 + col], w3c = params[RGF_W3 + 256 + col];
+  const float w3l1 = block_max((fabsf(w3a) + fabsf(w3b)) + fabsf(w3c), red4, tid) * 1.0001f;
+  const int ew3 = scale_exp(block_max(fmaxf(fmaxf(fabsf(w3a), fabsf(w3b)), fabsf(w3c)), red4, tid));
+  pp_half8 a3h, a3l;
+  {
+    const float z = 0.f;
+    const float4 wa = lh == 0 ? make_float4(w3a, w3b, w3c, z) : make_float4(z, z, z, z);
+    split8(wa, make_float4(z, z, z, z), pow2(ew3), a3h, a3l);
+  }
+  const int j0 = tid & 127, h0 = tid >> 7;
+  float wacc3[3] = {0.f, 0.f, 0.f}, bacc3 = 0.f;
+
+  auto stage_tile = [&](const float* __restrict__ X, int r0, float* dst) {       // [64][128] fp32, rows clamped to R - 1
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = 16 * wid + 2 * i;
+      const int row = min(r0 + rl + lh, R - 1);
+      __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(X + (size_t)row * 128 + l31 * 4), PP_LDS_PTR(dst + rl * 128), 16, 0, 0);
+    }
+  };
+  auto stage = [&](int t, int b) {              // H2 rows, rgb and rgb_grad of tile t
+    const int r0 = t * TILE_ROWS;
+    stage_tile(H2, r0, XS);
+    if (wid < 3) {
+      const int e = min(r0 * 3 + tid, R * 3 - 1);
+      __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(rgb + e), PP_LDS_PTR(&RG[b][0][wid * 64]), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(rgb_grad + e), PP_LDS_PTR(&RG[b][1][wid * 64]), 4, 0, 0);
+    }
+  };
+  // d loss / d logit = rgb_grad * rgb * (1 - rgb); zero for rows past the end; its largest magnitude into the tile's slot
+  auto logit_grads = [&](int t, int b) {
+    const int r0 = t * TILE_ROWS;
+    float gl = 0.f;
+    if (tid < 192) {
+      const int m = tid / 3, o = tid - 3 * m;
+      const float r = RG[b][0][tid];
+      gl = (r0 + m < R) ? RG[b][1][tid] * r * (1.f - r) : 0.f;
+      GL[m * 4 + o] = gl;
+      if (logit_grad && r0 + m < R) logit_grad[(size_t)(r0 + m) * lg_ld + o] = gl;
+    } else {
+      GL[(tid - 192) * 4 + 3] = 0.f;
+    }
+    slot_max(&Mx[b][4], fabsf(gl), lane);
+  };
+  // W3bar / b3bar of the staged tile (thread = feature j0, rows of half h0)
+  auto w3_accumulate = [&]() {
+    const float* __restrict__ xs = &XS[(h0 * 32) * 128 + j0];
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      const float4 g = *reinterpret_cast<const float4*>(&GL[(h0 * 32 + r) * 4]);
+      const float x = xs[r * 128];
+      wacc3[0] = fmaf(g.x, x, wacc3[0]); wacc3[1] = fmaf(g.y, x, wacc3[1]); wacc3[2] = fmaf(g.z, x, wacc3[2]);
+      if (j0 < 3) bacc3 += GL[(h0 * 32 + r) * 4 + j0];
+    }
+  };
+  // Ybar2 of the staged tile (parity b) into LDS tile `dst` and `ybar`: both halves; sets the exponent of the image
+  int e2n = 0;
+  auto out_layer_bwd = [&](int t, int b, _Float16* dst) {
+    const float gmx = slot_get(&Mx[b][4]);
+    const int eg = scale_exp(gmx);
+    const int e2 = scale_exp(gmx * w3l1);
+    const float sg = pow2(eg), s2 = pow2(e2), inv = pow2(-(eg + ew3)), n2 = pow2(-e2);
+    const int r0 = t * TILE_ROWS;
+    float* crow = ybar + (size_t)(r0 + l31) * 128 + fb;
+    HalfEpilogueB<true> eb;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      float4 x = *reinterpret_cast<const float4*>(&GL[(hh * 32 + l31) * 4]);
+      if (lh != 0) x = make_float4(0.f, 0.f, 0.f, 0.f);
+      pp_half8 xh, xl;
+      split8(x, make_float4(0.f, 0.f, 0.f, 0.f), sg, xh, xl);
+      f32x16 a;
+      zero16(a);
+      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3h, xl, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3l, xh, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3h, xh, a, 0, 0, 0);
+      eb.begin(&XS[(hh * 32 + l31) * 128 + fb]);
+      eb.all(a, inv, s2, r0 + hh * 32 + l31 < R, crow + hh * 32 * 128, dst + (hh * 32 + l31) * LDH2 + fb);
+      slot_max(&Mx[b][hh], eb.vmax(n2), lane);
+    }
+    e2n = e2;
+  };
+
+  if (tid < 16) Mx[tid >> 3][tid & 7] = 0u;
+  stage(blockIdx.x, 0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  logit_grads(blockIdx.x, 0);
+  __syncthreads();
+  w3_accumulate();
+  out_layer_bwd(blockIdx.x, 0, At[0]);
+  __syncthreads();
+
+  int par = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
+    const int r0 = tile * TILE_ROWS;
+    const int tnext = tile + gridDim.x;
+    const bool more = tnext < ntiles;
+    const bool ok0 = r0 + l31 < R, ok1 = r0 + 32 + l31 < R;
+    _Float16* const Aa = At[par];                // holds Ybar2 of this tile, later Ybar0
+    _Float16* const Ab = At[par ^ 1];            // Ybar1, later the next tile's Ybar2
+    const int e2 = e2n;
+    float* const crow = ybar + (size_t)(r0 + l31) * 128 + fb;
+    f32x16 acc0, acc1;
+    HalfEpilogueB<true> eb;
+    if (tid < 5) Mx[par ^ 1][tid] = 0u;
+    if (more) stage(tnext, par ^ 1);             // XS / RG[par^1]: consumed at the bottom of this iteration
+    stage_tile(H1, r0, GT);
+    // ---- layer 2 on half 0
+    zero16(acc0);
+    mma_half(Aa, w2, acc0, l31, lh);
+    PP_WAIT_VMEM();
+    __syncthreads();                             // gates come from all four wavefronts' loads
+    // ---- layer 2 on half 1  ||  epilogue of (Ybar1, half 0)
+    const int e10 = scale_exp(slot_get(&Mx[par][0]) * l1_2), e11 = scale_exp(slot_get(&Mx[par][1]) * l1_2);
+    zero16(acc1);
+    eb.begin(&GT[l31 * 128 + fb]);
+    mma_half(Aa + 32 * LDH2, w2, acc1, l31, lh, [&](int ks) {
+      eb.step(ks, acc0, pow2(-(e2 + ew2)), pow2(e10), ok0, crow + LS, Ab + l31 * LDH2 + fb);
+    });
+    slot_max(&Mx[par][2], eb.vmax(pow2(-e10)), lane);
+    __syncthreads();
+    // ---- layer 1 on half 0  ||  epilogue of (Ybar1, half 1)
+    zero16(acc0);
+    eb.begin(&GT[(32 + l31) * 128 + fb]);
+    mma_half(Ab, w1, acc0, l31, lh, [&](int ks) {
+      eb.step(ks, acc1, pow2(-(e2 + ew2)), pow2(e11), ok1, crow + LS + 32 * 128, Ab + (32 + l31) * LDH2 + fb);
+    });
+    slot_max(&Mx[par][3], eb.vmax(pow2(-e11)), lane);
+    __syncthreads();                             // GT (H1) is free
+    stage_tile(H0, r0, GT);
+    // ---- layer 1 on half 1 (the H0 gates land meanwhile)
+    zero16(acc1);
+    mma_half(Ab + 32 * LDH2, w1, acc1, l31, lh);
+    PP_WAIT_VMEM();
+    __syncthreads();
+    // ---- epilogues of Ybar0 (image into tile Aa: the operand of the feature-gradient product)
+    const int e00 = scale_exp(slot_get(&Mx[par][2]) * l1_1), e01 = scale_exp(slot_get(&Mx[par][3]) * l1_1);
+    eb.begin(&GT[l31 * 128 + fb]);
+    eb.all(acc0, pow2(-(e10 + ew1)), pow2(e00), ok0, crow + 2 * LS, Aa + l31 * LDH2 + fb);
+    eb.begin(&GT[(32 + l31) * 128 + fb]);
+    eb.all(acc1, pow2(-(e11 + ew1)), pow2(e01), ok1, crow + 2 * LS + 32 * 128, Aa + (32 + l31) * LDH2 + fb);
+    if (more) logit_grads(tnext, par ^ 1);
+    __syncthreads();
+    // ---- layer 0: feat_grad = Ybar0 . W0   (32 rows x 32 features per wavefront)
+    {
+      f32x16 fa;
+      zero16(fa);
+      mma_half(Aa + rb * 32 * LDH2, w0, fa, l31, lh);
+      const float inv = pow2(-((rb ? e01 : e00) + ew0));
+      const int row = r0 + rb * 32 + l31;
+      if (row < R) {
+        float* __restrict__ ft = feat_grad + (size_t)row * 64 + (wid & 1) * 32 + 4 * lh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(ft + 8 * q) = make_float4(fa[4 * q] * inv, fa[4 * q + 1] * inv, fa[4 * q + 2] * inv, fa[4 * q + 3] * inv);
+      }
+    }
+    // ---- the next tile's output-layer backward into tile Ab (last read by the layer-1 MFMAs)
+    if (more) {
+      w3_accumulate();
+      out_layer_bwd(tnext, par ^ 1, Ab);
+    }
+    __syncthreads();
+  }
+
+  // ---- flush W3bar, b3bar (thread = feature / output)
+  float* red = reinterpret_cast<float*>(At[0]);
+  __syncthreads();
+  if (h0 == 1) {
+#pragma unroll
+    for (int o = 0; o < 3; ++o) red[o * 128 + j0] = wacc3[o];
+    if (j0 < 3) red[4 * 128 + j0] = bacc3;
+  }
+  __syncthreads();
+  if (h0 == 0) {
+#pragma unroll
+    for (int o = 0; o < 3; ++o) atomicAdd(&params_grad[RGF_W3 + o * 128 + j0], wacc3[o] + red[o * 128 + j0]);
+    if (j0 < 3) atomicAdd(&params_grad[RGF_B3 + j0], bacc3 + red[4 * 128 + j0]);
+  }
+  (void)l1_dummy;
+}
+
+int pp_launch_rgb_fused_bwd_s(const float* params, const float* acts, const float* rgb, const float* rgb_grad,
+                              const int32_t* count, int capacity, float* ybar, float* params_grad, float* feat_grad,
+                              float* logit_grad, int lg_ld, hipStream_t st) {
+  const int ntiles = pp_div_up(capacity, TILE_ROWS);
+  const int grid = ntiles < PP_FUSED_WGS ? ntiles : PP_FUSED_WGS;
+  hipLaunchKernelGGL(k_rgb_fused_bwd_s, dim3(grid), dim3(256), 0, st, params, acts, rgb, rgb_grad, count, capacity, ybar,
+                     params_grad, feat_grad, logit_grad, lg_ld);
+  return 0;
+}
