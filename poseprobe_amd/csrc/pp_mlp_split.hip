@@ -202,37 +202,39 @@ struct HalfEpilogue {
         if (COLS == 4) asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(y[e]) : "v"(p[e]), "v"(y[e]));          // y & ~mask
         else y[e] = fmaxf(y[e], 0.f);
       }
-    } else if (i == 3) {
-      if (ok && MS_DBG != 2) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(Crow + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
-      }
-      if (!SPLIT) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(Arow) + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
-      }
-    } else if (SPLIT && i == 4) {
+    } else if (SPLIT && i == 3) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) p[e] = y[e] * snext;
-    } else if (SPLIT && i == 5) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h[k]) : "v"(p[2 * k]), "v"(p[2 * k + 1]));
         asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(xmax) : "v"(p[2 * k]), "v"(p[2 * k + 1]));
       }
-    } else if (SPLIT && i == 6) {
+    } else if (SPLIT && i == 4) {
       // lo = x - hi: fp32 fma on the f16 hi half, rounded once into the packed result
 #pragma unroll
       for (int k = 0; k < 8; ++k) asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l[k]) : "v"(h[k]), "v"(p[2 * k]));
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[k]) : "v"(h[k]), "v"(p[2 * k + 1]));
-    } else if (SPLIT && i == 7 && MS_DBG != 3) {
+    } else if (i == 5) {
+      // the LDS image two steps before the end of the stage: its writes have retired when the barrier's lgkmcnt(0) comes
+      if (SPLIT && MS_DBG != 3) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<uint2*>(Arow + 8 * q) = make_uint2(h[2 * q], h[2 * q + 1]);
-        *reinterpret_cast<uint2*>(Arow + 8 * q + PLANE) = make_uint2(l[2 * q], l[2 * q + 1]);
+        for (int q = 0; q < 4; ++q) {
+          *reinterpret_cast<uint2*>(Arow + 8 * q) = make_uint2(h[2 * q], h[2 * q + 1]);
+          *reinterpret_cast<uint2*>(Arow + 8 * q + PLANE) = make_uint2(l[2 * q], l[2 * q + 1]);
+        }
+      }
+      if (!SPLIT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(Arow) + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+      }
+    } else if (i == 6) {
+      if (ok && MS_DBG != 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(Crow + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -561,36 +563,38 @@ struct HalfEpilogueB {
     } else if (i == 2) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) asm volatile("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(y[e]) : "v"(y[e]), "s"(m[e]));
-    } else if (i == 3) {
-      if (Crow != nullptr && ok) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(Crow + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
-      }
-      if (!SPLIT) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(Arow) + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
-      }
-    } else if (SPLIT && i == 4) {
+    } else if (SPLIT && i == 3) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) p[e] = y[e] * snext;
-    } else if (SPLIT && i == 5) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h[k]) : "v"(p[2 * k]), "v"(p[2 * k + 1]));
         asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(xmax) : "v"(p[2 * k]), "v"(p[2 * k + 1]));
       }
-    } else if (SPLIT && i == 6) {
+    } else if (SPLIT && i == 4) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l[k]) : "v"(h[k]), "v"(p[2 * k]));
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[k]) : "v"(h[k]), "v"(p[2 * k + 1]));
-    } else if (SPLIT && i == 7) {
+    } else if (i == 5) {
+      if (SPLIT) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<uint2*>(Arow + 8 * q) = make_uint2(h[2 * q], h[2 * q + 1]);
-        *reinterpret_cast<uint2*>(Arow + 8 * q + PLANE) = make_uint2(l[2 * q], l[2 * q + 1]);
+        for (int q = 0; q < 4; ++q) {
+          *reinterpret_cast<uint2*>(Arow + 8 * q) = make_uint2(h[2 * q], h[2 * q + 1]);
+          *reinterpret_cast<uint2*>(Arow + 8 * q + PLANE) = make_uint2(l[2 * q], l[2 * q + 1]);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(Arow) + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+      }
+    } else if (i == 6) {
+      // HBM copy last: the loads a stage issues after this step (step 7 is left to the caller) are then the youngest memory
+      // operations, and a vmcnt(0) placed before step 6 of the NEXT stage waits for nothing younger than them
+      if (Crow != nullptr && ok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(Crow + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -774,8 +778,8 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd_s(const float* __restric
     zero16(acc1);
     eb.begin(grow0);
     mma_half(&At[0][32 * LDH2], w3, acc1, l31, lh, [&](int ks) {
-      if (ks < 2) stage_gate_piece(X1, r0, 1, ks);
       eb.step(ks, acc0, pow2(-(e30 + ew3)), pow2(e20), ok0, crow + LS, arow1);
+      if (ks == 7) { stage_gate_piece(X1, r0, 1, 0); stage_gate_piece(X1, r0, 1, 1); }      // after the stage's stores
     });
     slot_max(&Mx[par][2], eb.vmax(pow2(-e20)), lane);
     __syncthreads();
@@ -783,27 +787,27 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd_s(const float* __restric
     zero16(acc0);
     eb.begin(grow0 + 8 * 128);
     mma_half(&At[1][0], w2, acc0, l31, lh, [&](int ks) {
+      if (ks == 5) PP_WAIT_VMEM();               // the X1 gates (and nothing younger: this stage's stores come in step 6)
       eb.step(ks, acc1, pow2(-(e31 + ew3)), pow2(e21), ok1, crow + LS + 32 * 128, arow1 + 32 * LDH2);
     });
     slot_max(&Mx[par][3], eb.vmax(pow2(-e21)), lane);
-    PP_WAIT_VMEM();
     __syncthreads();
     // ---- stage B2: layer 2 on half 1  ||  epilogue of (Ybar1, half 0); loads: gates X0 -> GT[0]
     const int e10 = scale_exp(slot_get(&Mx[par][2]) * l1_2), e11 = scale_exp(slot_get(&Mx[par][3]) * l1_2);
     zero16(acc1);
     eb.begin(grow1);
     mma_half(&At[1][32 * LDH2], w2, acc1, l31, lh, [&](int ks) {
-      if (ks < 2) stage_gate_piece(X0, r0, 0, ks);
       eb.step(ks, acc0, pow2(-(e20 + ew2)), pow2(e10), ok0, crow + 2 * LS, arow0);
+      if (ks == 7) { stage_gate_piece(X0, r0, 0, 0); stage_gate_piece(X0, r0, 0, 1); }
     });
     __syncthreads();
     // ---- stage A1: layer 1 on half 0  ||  epilogue of (Ybar1, half 1)
     zero16(acc0);
     eb.begin(grow1 + 8 * 128);
     mma_half(&At[0][0], w1, acc0, l31, lh, [&](int ks) {
+      if (ks == 5) PP_WAIT_VMEM();               // the X0 gates
       eb.step(ks, acc1, pow2(-(e21 + ew2)), pow2(e11), ok1, crow + 2 * LS + 32 * 128, arow0 + 32 * LDH2);
     });
-    PP_WAIT_VMEM();
     __syncthreads();
     // ---- stage B1: layer 1 on half 1  ||  epilogue of (Ybar0, half 0) into the fp32 view; then that of half 1
     HalfEpilogueB<false> ef;
