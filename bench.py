@@ -565,7 +565,7 @@ def main():
     from poseprobe_amd import _lib
     split_bits = _lib.get_option('mlp_split') if _lib.get_option('mlp_fused') else 0
     split_of = {'k_warp_fused_fwd': split_bits & 1, 'k_warp_fused_bwd': split_bits & 2, 'k_rgb_fused_fwd': split_bits & 4,
-                'k_rgb_fused_bwd': split_bits & 8}
+                'k_rgb_fused_bwd': split_bits & 8, 'k_wgrad_chain<128> (warp)': split_bits & 16, 'k_wgrad_chain<64> (rgbnet)': split_bits & 16}
 
     def price(name, fl, ms, samples):
         tf = fl * samples / (ms * 1e-3) / 1e12

@@ -27,7 +27,7 @@ enum PPOption {
   PP_OPT_NERF_BN,              // scene branch: 256 selects the 128 x 256 tile of the fp32 NT GEMM
   PP_OPT_NERF_PLANES,          // scene branch: 1 = activations travel as pre-split fp16 hi / lo planes (pp_gemm_planes.h)
   PP_OPT_SDF_INDEX_EXACT,      // 1: exact voxel indices in the custom SDF sampler; 0 (default): the reference's fp32 flat index
-  PP_OPT_MLP_SPLIT,            // bit mask: layer-fused object-branch MLP kernels with three fp16 products per fp32 product (pp_mlp_split.hip); 1 warp fwd, 2 warp bwd, 4 rgb fwd, 8 rgb bwd
+  PP_OPT_MLP_SPLIT,            // bit mask: layer-fused object-branch MLP kernels with three fp16 products per fp32 product (pp_mlp_split.hip); 1 warp fwd, 2 warp bwd, 4 rgb fwd, 8 rgb bwd, 16 weight-gradient chains
   PP_OPT_COUNT
 };
 int pp_opt(int id);

@@ -25,6 +25,16 @@ int pp_launch_warp_fused_fwd(const float* params, const float* pts, const int32_
 int pp_launch_warp_fused_bwd(const float* params, const float* pts, const float* acts, const float* out_grad,
                              const int32_t* count, int capacity, float out_range, float* ybar, float* params_grad,
                              float* pts_grad, hipStream_t st);
+// operands of one layer of the weight-gradient chain (split-precision kernel, pp_mlp_split.hip)
+struct WgradOperands {
+  const float* Y;      // [R][128]  gradient w.r.t. the layer's pre-activation (already gated)
+  const float* X;      // [R][KX]   input activations of the layer
+  float* Wbar;         // [128][KX]
+  float* bbar;         // [128] or nullptr: += column sums of Y (every row, or the primal rows of the 4-row form)
+};
+int pp_launch_wgrad_chain_s(const float* YA, const float* XA, float* WA, const float* YB, const float* XB, float* WB,
+                            const float* YC, const float* XC, float* WC, int kxc, const int32_t* count, int rmul, int rcap,
+                            hipStream_t st, float* bA, float* bB, float* bC);
 // split-precision variants (pp_mlp_split.hip, option "mlp_split"): same contracts
 int pp_launch_warp_fused_fwd_s(const float* params, const float* pts, const int32_t* count, int capacity, float out_range,
                                float* acts, float* out, hipStream_t st);

@@ -1350,3 +1350,278 @@ int pp_launch_rgb_fused_bwd_s(const float* params, const float* acts, const floa
                      params_grad, feat_grad, logit_grad, lg_ld);
   return 0;
 }
+
+// ================================================================================================ weight gradients
+// Wbar_l[n][k] += sum_r Ybar_l[r][n] * X_l[r][k] for three layers in ONE launch, as k_wgrad_chain (pp_mlp_fused.hip: a step = one
+// 64-row tile of one layer, both operand tiles by LDS-direct loads into a double buffer, the accumulators resident over the
+// work-group's whole row range) - with the product on the fp16 MFMAs, three per fp32 product.
+// The reduction runs over ROWS, so an operand fragment is 8 consecutive rows of one column: a lane gathers them from the row-major
+// fp32 tile (conflict-free: consecutive lanes read consecutive columns; two rows per ds_read2st64_b32), scales, splits, and feeds
+// them to the MFMAs - 20 vector instructions per fragment, issued between the MFMAs of the previous 16-row group.
+// Scale: one power of two per operand for a wavefront's whole row range (its accumulators see every tile), kept as a RUNNING
+// exponent: the magnitudes of every 16-row group's fragments are checked against what the running scale can hold before they are
+// converted (v_max3 + one ballot); a group that exceeds it lowers the exponent (with a factor 4 of headroom) and the accumulators
+// are rescaled by the exact power of two - a handful of times per launch.  Rows far below the running maximum are converted with
+// its absolute floor (2^-40 of it), which is what a sum needs.
+namespace {
+
+// piece i of 8 of the LDS-direct loads of one tile pair (Y: two 512-byte rows; X: two rows, or four 256-byte rows on the first
+// four pieces when KX == 64)
+template <int KX>
+__device__ __forceinline__ void wgs_issue_piece(const WgradOperands& L, int r0, int R, float* Ybuf, float* Xbuf, int wid, int lane, int i) {
+  const int l31 = lane & 31, lh = lane >> 5;
+  {
+    const int rl = 16 * wid + 2 * i;
+    const int row = min(r0 + rl + lh, R - 1);
+    __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(L.Y + (size_t)row * 128 + l31 * 4), PP_LDS_PTR(Ybuf + rl * 128), 16, 0, 0);
+  }
+  if (KX == 128) {
+    const int rl = 16 * wid + 2 * i;
+    const int row = min(r0 + rl + lh, R - 1);
+    __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(L.X + (size_t)row * 128 + l31 * 4), PP_LDS_PTR(Xbuf + rl * 128), 16, 0, 0);
+  } else if (i < 4) {
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int rl = 16 * wid + 4 * i;
+    const int row = min(r0 + rl + lq, R - 1);
+    __builtin_amdgcn_global_load_lds(PP_GLOBAL_PTR(L.X + (size_t)row * 64 + l15 * 4), PP_LDS_PTR(Xbuf + rl * 64), 16, 0, 0);
+  }
+}
+template <int KX>
+__device__ __forceinline__ void wgs_issue(const WgradOperands& L, int r0, int R, float* Ybuf, float* Xbuf, int wid, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) wgs_issue_piece<KX>(L, r0, R, Ybuf, Xbuf, wid, lane, i);
+}
+
+// eight consecutive rows of one column, scaled and split (v: the raw values, kept for the bias sums)
+__device__ __forceinline__ void frag_split(const float (&v)[8], float s, pp_half8& h, pp_half8& l) {
+  unsigned hh[4], ll[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float x0 = v[2 * k] * s, x1 = v[2 * k + 1] * s;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hh[k]) : "v"(x0), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ll[k]) : "v"(hh[k]), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(ll[k]) : "v"(hh[k]), "v"(x1));
+  }
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const u4 hv = {hh[0], hh[1], hh[2], hh[3]}, lv = {ll[0], ll[1], ll[2], ll[3]};
+  h = __builtin_bit_cast(pp_half8, hv);
+  l = __builtin_bit_cast(pp_half8, lv);
+}
+
+// state of one wavefront: running scale exponents of its Y / X fragments (a wavefront's accumulators only ever see its own
+// fragments, so the scales are per wavefront and need no work-group-wide maximum), bias partial sums
+struct WgsLayer {
+  int eY, eX;
+  float bsum[2];
+};
+
+// largest magnitude of the fragments against what the running scale can hold; true if any lane exceeds it
+template <int NF>
+__device__ __forceinline__ bool frag_exceeds(const float (&v)[NF][8], float lim, float& m) {
+  m = 0.f;
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(v[f][2 * k]), "v"(v[f][2 * k + 1]));
+  return __builtin_amdgcn_ballot_w64(m > lim) != 0ull;
+}
+
+// 64 rows x (64 x 32 NB) outputs of one wavefront: acc[t][u] += Y[:, 64 wr + 32 t + .]^T X[:, 32 NB wc + 32 u + .]; issue(i), i = 0..7,
+// is called between the MFMA groups of the first two 16-row groups (the next tile's loads ride there).
+// Group -1 only converts.  Cold path: a fragment that exceeds the running scale lowers the exponent, with a factor 4 of headroom,
+// and rescales the accumulators by the exact power of two.  (A rolled loop over the groups would hold one copy of it instead of
+// ten, but measures 2.2 x slower: the copies of the fragments between iterations and the uniform branches defeat the scheduling.)
+template <int KX, int CSTEP, class Issue>
+__device__ __forceinline__ void wgs_compute(const float* __restrict__ Ybuf, const float* __restrict__ Xbuf, f32x16 (&acc)[2][KX / 64],
+                                            WgsLayer& st, bool bias, int wr, int wc, int l31, int lh, Issue issue) {
+  constexpr int NB = KX / 64;
+  float sY = pow2(st.eY), sX = pow2(st.eX), limY = pow2(15 - st.eY), limX = pow2(15 - st.eX);
+  const float* yp = Ybuf + (8 * lh) * 128 + 64 * wr + l31;
+  const float* xp = Xbuf + (8 * lh) * KX + 32 * NB * wc + l31;
+  float ry[2][8], rx[NB][8];
+  pp_half8 ah[2] = {}, al[2] = {}, bh[NB] = {}, bl[NB] = {};
+  auto rescale = [&](int d) {
+    const float f = pow2(d);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][u][i] *= f;
+  };
+#pragma unroll
+  for (int ks = -1; ks < 4; ++ks) {
+    pp_half8 ch[2] = {ah[0], ah[1]}, cl[2] = {al[0], al[1]}, dh[NB], dl[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) { dh[u] = bh[u]; dl[u] = bl[u]; }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks < 3) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ry[t][j] = yp[(16 * (ks + 1) + j) * 128 + 32 * t];
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rx[u][j] = xp[(16 * (ks + 1) + j) * KX + 32 * u];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks >= 0) {
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        acc[0][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[0], dh[u], acc[0][u], 0, 0, 0);
+        acc[0][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[0], dl[u], acc[0][u], 0, 0, 0);
+        acc[0][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[0], dh[u], acc[0][u], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks >= 0 && ks < 2) { issue(4 * ks); issue(4 * ks + 1); issue(4 * ks + 2); issue(4 * ks + 3); }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks >= 0) {
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        acc[1][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[1], dh[u], acc[1][u], 0, 0, 0);
+        acc[1][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[1], dl[u], acc[1][u], 0, 0, 0);
+        acc[1][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[1], dh[u], acc[1][u], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next group's fragments, converted while the MFMAs above run.  The scale checks come AFTER both MFMA groups of this
+    // 16-row group: a rescale between them would add the second group's products, still at the old scale, to rescaled sums.
+    if (ks < 3) {
+      float m;
+      if (frag_exceeds<2>(ry, limY, m)) {                        // cold
+        const int e = scale_exp(wave_max(m)) - 2;
+        rescale(e - st.eY);
+        st.eY = e; sY = pow2(e); limY = pow2(15 - e);
+      }
+      if (frag_exceeds<NB>(rx, limX, m)) {                       // cold
+        const int e = scale_exp(wave_max(m)) - 2;
+        rescale(e - st.eX);
+        st.eX = e; sX = pow2(e); limX = pow2(15 - e);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (bias) {               // column sums of Y over the rows that count (every row / the primal rows of the 4-row form)
+#pragma unroll
+          for (int j = 0; j < 8; j += CSTEP) st.bsum[t] += ry[t][j];
+        }
+        frag_split(ry[t], sY, ah[t], al[t]);
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) frag_split(rx[u], sX, bh[u], bl[u]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+}  // namespace
+
+// One work-group works on ONE layer (blockIdx.y) - the three layers share nothing, and 64 resident accumulators instead of 192
+// leave the registers the conversion needs; the persistent work-groups of a layer walk its tiles from the end of the row range
+// (what the data-gradient kernel wrote last is what the Infinity Cache still holds).
+template <int KX, int CSTEP>
+__device__ __forceinline__ void wgs_layer(const WgradOperands& L, int R, int ntiles, float* __restrict__ Yb0, float* __restrict__ Xb0,
+                                          float* __restrict__ Yb1, float* __restrict__ Xb1) {
+  constexpr int NB = KX / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, lh = lane >> 5;
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < NB; ++u) zero16(acc[t][u]);
+  WgsLayer st = {60, 60, {0.f, 0.f}};
+  const bool bias = L.bbar != nullptr && wc == 0;
+  // after the loads of a tile have landed: zero the Y rows past R (last tile only)
+  auto prepare = [&](int r0, float* Ybuf) {
+    if (r0 + TILE_ROWS > R) {
+      for (int i = tid; i < TILE_ROWS * 128; i += 256)
+        if (r0 + (i >> 7) >= R) Ybuf[i] = 0.f;
+      __syncthreads();
+    }
+  };
+  const int first = ntiles - 1 - (int)blockIdx.x;
+  wgs_issue<KX>(L, first * TILE_ROWS, R, Yb0, Xb0, wid, lane);
+  // two tiles per iteration keep the buffer assignment static
+#ifdef MS_TIMERS
+  unsigned long long tsum[16] = {0}, tprev = __builtin_readcyclecounter();
+#endif
+  for (int t0 = first; t0 >= 0; t0 -= 2 * (int)gridDim.x) {
+    const int t1 = t0 - (int)gridDim.x, t2 = t1 - (int)gridDim.x;
+    TICK(4);
+    PP_WAIT_VMEM(); __syncthreads();
+    TICK(0);
+    prepare(t0 * TILE_ROWS, Yb0);
+    TICK(1);
+    TICK(2);
+    wgs_compute<KX, CSTEP>(Yb0, Xb0, acc, st, bias, wr, wc, l31, lh, [&](int i) {
+      if (t1 >= 0) wgs_issue_piece<KX>(L, t1 * TILE_ROWS, R, Yb1, Xb1, wid, lane, i);
+    });
+    TICK(3);
+    if (t1 < 0) break;
+    PP_WAIT_VMEM(); __syncthreads();
+    TICK(0);
+    prepare(t1 * TILE_ROWS, Yb1);
+    TICK(1);
+    TICK(2);
+    wgs_compute<KX, CSTEP>(Yb1, Xb1, acc, st, bias, wr, wc, l31, lh, [&](int i) {
+      if (t2 >= 0) wgs_issue_piece<KX>(L, t2 * TILE_ROWS, R, Yb0, Xb0, wid, lane, i);
+    });
+    TICK(3);
+  }
+#ifdef MS_TIMERS
+  if (tid == 0)
+    for (int i = 0; i < 16; ++i) atomicAdd(&g_ms_t[i], tsum[i]);
+#endif
+  // flush: one atomic per entry, scaled back
+  const float f = pow2(-(st.eY + st.eX));
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int k = 32 * NB * wc + u * 32 + l31;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int n = wr * 64 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        atomicAdd(&L.Wbar[(size_t)n * KX + k], acc[t][u][reg] * f);
+      }
+    }
+  if (bias) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float v = st.bsum[t] + __shfl_xor(st.bsum[t], 32, 64);
+      if (lh == 0) atomicAdd(&L.bbar[64 * wr + 32 * t + l31], v);
+    }
+  }
+}
+
+template <int KXC, int CSTEP>
+__global__ __launch_bounds__(256) void k_wgrad_chain_s(WgradOperands LA, WgradOperands LB, WgradOperands LC,
+                                                       const int32_t* __restrict__ count, int rmul, int rcap) {
+  __shared__ __attribute__((aligned(16))) float Yb0[TILE_ROWS * 128];
+  __shared__ __attribute__((aligned(16))) float Xb0[TILE_ROWS * 128];
+  __shared__ __attribute__((aligned(16))) float Yb1[TILE_ROWS * 128];
+  __shared__ __attribute__((aligned(16))) float Xb1[TILE_ROWS * 128];
+  const int R = min(count[0] * rmul, rcap);
+  const int ntiles = (R + TILE_ROWS - 1) / TILE_ROWS;
+  if ((int)blockIdx.x >= ntiles) return;
+  // one copy of the layer code per operand width (three calls would triple the instruction footprint)
+  const WgradOperands L = blockIdx.y == 0 ? LA : (blockIdx.y == 1 ? LB : LC);
+  if (KXC == 128 || blockIdx.y < 2) wgs_layer<128, CSTEP>(L, R, ntiles, Yb0, Xb0, Yb1, Xb1);
+  else wgs_layer<KXC, CSTEP>(L, R, ntiles, Yb0, Xb0, Yb1, Xb1);
+}
+
+int pp_launch_wgrad_chain_s(const float* YA, const float* XA, float* WA, const float* YB, const float* XB, float* WB,
+                            const float* YC, const float* XC, float* WC, int kxc, const int32_t* count, int rmul, int rcap,
+                            hipStream_t st, float* bA, float* bB, float* bC) {
+  WgradOperands LA{YA, XA, WA, bA}, LB{YB, XB, WB, bB}, LC{YC, XC, WC, bC};
+  const int ntiles = pp_div_up(rcap, TILE_ROWS);
+  const int per_layer = PP_FUSED_WGS / 3;                           // persistent work-groups per layer: at most one per CU over the three layers
+  const int gx = ntiles < per_layer ? ntiles : per_layer;
+  if (kxc == 128)
+    hipLaunchKernelGGL((k_wgrad_chain_s<128, 4>), dim3(gx, 3), dim3(256), 0, st, LA, LB, LC, count, rmul, rcap);
+  else
+    hipLaunchKernelGGL((k_wgrad_chain_s<64, 1>), dim3(gx, 3), dim3(256), 0, st, LA, LB, LC, count, rmul, rcap);
+  return 0;
+}

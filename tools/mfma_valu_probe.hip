@@ -53,6 +53,21 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, long long* cyc) 
         if (N > 1) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(*(double*)&v2));
         if (N > 2) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(*(double*)&v4));
         if (N > 3) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(*(double*)&v6));
+      } else if (KIND == 6) {   // mixed-precision fma into a packed half
+        if (N > 0) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(v0) : "v"(v4), "v"(v5));
+        if (N > 1) asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v0) : "v"(v4), "v"(v6));
+        if (N > 2) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(v1) : "v"(v4), "v"(v5));
+        if (N > 3) asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v1) : "v"(v4), "v"(v6));
+        if (N > 4) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(v2) : "v"(v4), "v"(v5));
+        if (N > 5) asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v2) : "v"(v4), "v"(v6));
+        if (N > 6) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(v3) : "v"(v4), "v"(v5));
+        if (N > 7) asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v3) : "v"(v4), "v"(v6));
+      } else if (KIND == 7) {   // ds_read2_b32 (two rows of a column)
+        if (N > 0) asm volatile("ds_read2_b32 %0, %1 offset1:128" : "=v"(*(double*)&v0) : "v"(la) : "memory");
+        if (N > 1) asm volatile("ds_read2_b32 %0, %1 offset0:1 offset1:129" : "=v"(*(double*)&v2) : "v"(la) : "memory");
+        if (N > 2) asm volatile("ds_read2_b32 %0, %1 offset0:2 offset1:130" : "=v"(*(double*)&v4) : "v"(la) : "memory");
+        if (N > 3) asm volatile("ds_read2_b32 %0, %1 offset0:3 offset1:131" : "=v"(*(double*)&v6) : "v"(la) : "memory");
+        if (N > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       } else if (KIND == 5) {   // f16 conversions
         if (N > 0) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(v0) : "v"(v4), "v"(v5));
         if (N > 1) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(v1) : "v"(v4), "v"(v5));
@@ -91,5 +106,7 @@ int main() {
   run<1, 3>("ds_write", out, cyc); run<2, 3>("ds_write", out, cyc);
   run<2, 4>("pk_fma", out, cyc); run<4, 4>("pk_fma", out, cyc);
   run<2, 5>("cvt", out, cyc); run<4, 5>("cvt", out, cyc);
+  run<4, 6>("fma_mix", out, cyc); run<8, 6>("fma_mix", out, cyc);
+  run<2, 7>("ds_read2", out, cyc); run<4, 7>("ds_read2", out, cyc);
   return 0;
 }
