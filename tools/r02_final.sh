@@ -7,4 +7,4 @@ echo bench done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02_final_prof -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-psnr > $R/gpurun_out/r02_final_bench_under_rocprof.json 2> $R/gpurun_out/r02_final_prof.err || { tail -5 $R/gpurun_out/r02_final_prof.err; exit 1; }
 echo bench-prof done
-$R/tools/pmc_mlp.sh 15 && $R/tools/pmc_mlp.sh 0
+$R/tools/pmc_mlp.sh 31 && $R/tools/pmc_mlp.sh 0
