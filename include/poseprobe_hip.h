@@ -186,6 +186,17 @@ int pp_k0_scatter_packed(const pp_scene* sc, const float* packed, int32_t n_shar
 int pp_k0_scatter_samples(const pp_scene* sc, const float* pts, const int32_t* count, int32_t capacity,
                           const float* feat_grad, float* k0_grad_cl, uint8_t* touched /*optional*/, void* stream);
 
+/* Deterministic variants of the two scatters above: the (sample, corner) contributions are sorted by voxel (stable radix sort) and
+ * added per voxel in ascending (shard, sample, corner) order - bit-identical results for identical inputs, from run to run and
+ * between ranks that replay the same shards (float atomics retire in hardware order).  About 7 x the time of the atomic kernels:
+ * an option.  `work`: device memory of pp_k0_scatter_sorted_workspace(n_shards * capacity) bytes; grids up to 2^32 - 2 voxels. */
+int pp_k0_scatter_sorted_workspace(int64_t n_samples, int64_t* bytes);
+int pp_k0_scatter_samples_sorted(const pp_scene* sc, const float* pts, const int32_t* count, int32_t capacity,
+                                 const float* feat_grad, float* k0_grad_cl, uint8_t* touched /*optional*/, void* work,
+                                 int64_t work_bytes, void* stream);
+int pp_k0_scatter_packed_sorted(const pp_scene* sc, const float* packed, int32_t n_shards, int32_t capacity, float* k0_grad_cl,
+                                uint8_t* touched /*optional*/, void* work, int64_t work_bytes, void* stream);
+
 /* ---------------------------------------------------------------- colour features: DenseGrid.forward for k0
  * (lib/grid.py:47-58, zeros padding), BARF positional encoding of xyz and view (voxurf_coarse.py:721-732,
  * :1009-1025), normal (:1028-1030) -> feat[M,64] (57 used, zero padded).  k0 is stored channels-last

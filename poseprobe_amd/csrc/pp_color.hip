@@ -3,38 +3,7 @@
 // [M,64] operand for the rgbnet GEMM.  k0 lives channels-last [X,Y,Z,C]: each stencil corner is one contiguous
 // C*4-byte read (3 x 16 B for C=12) instead of C strided 4-byte reads of the reference's [1,C,X,Y,Z] layout.
 #include "pp_common.h"
-
-#define PP_FEAT_LD 64
-
-struct K0Tri {
-  float w0[3], w1[3];
-  int i0[3];
-  bool ok1[3];  // +1 corner inside the grid (zeros padding otherwise)
-  bool ok0[3];
-};
-
-__device__ __forceinline__ void k0_setup(const SceneDev& sc, const float p[3], K0Tri& t) {
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float u = pp_grid_u(p[a], sc.mn[a], sc.mx[a], sc.sz[a]);
-    float f = floorf(u);
-    t.w1[a] = pp_sub(u, f);
-    t.w0[a] = pp_sub(pp_add(f, 1.f), u);
-    float fc = fminf(fmaxf(f, -2.f), (float)sc.sz[a]);
-    int i = (int)fc;
-    t.i0[a] = i;
-    t.ok0[a] = (i >= 0) && (i < sc.sz[a]);
-    t.ok1[a] = (i + 1 >= 0) && (i + 1 < sc.sz[a]);
-  }
-}
-
-__device__ __forceinline__ bool k0_corner(const SceneDev& sc, const K0Tri& t, int c, size_t& off, float& w) {
-  bool ok = ((c & 4) ? t.ok1[0] : t.ok0[0]) && ((c & 2) ? t.ok1[1] : t.ok0[1]) && ((c & 1) ? t.ok1[2] : t.ok0[2]);
-  int ix = t.i0[0] + ((c >> 2) & 1), iy = t.i0[1] + ((c >> 1) & 1), iz = t.i0[2] + (c & 1);
-  off = (((size_t)ix * sc.sz[1] + iy) * sc.sz[2] + iz) * (size_t)sc.C;
-  w = ((c & 4) ? t.w1[0] : t.w0[0]) * ((c & 2) ? t.w1[1] : t.w0[1]) * ((c & 1) ? t.w1[2] : t.w0[2]);
-  return ok;
-}
+#include "pp_k0_tri.h"
 
 __device__ __forceinline__ float pp_norm3c(float x, float y, float z) { return sqrtf(fmaf(z, z, fmaf(y, y, x * x))); }
 
@@ -240,7 +209,6 @@ __global__ __launch_bounds__(256) void k_k0_scatter(SceneDev sc, const float* __
 // (bit pattern of an int32).  After one all-gather every rank replays the scatter for all shards into its own full
 // gradient grid.  DESIGN.md 7.
 // ------------------------------------------------------------------------------------------------------------------
-#define PP_PACK_LD 16
 __global__ __launch_bounds__(256) void k_k0_pack(const float* __restrict__ pts, const float* __restrict__ feat_grad,
                                                  const int32_t* __restrict__ count, int capacity, int C,
                                                  float* __restrict__ packed) {

@@ -173,8 +173,12 @@ class DistContext:
             from . import ops
             self._grid_work.wait()
             self._grid_work = None
-            ops.k0_scatter_packed(eng.cfg.pp, self._gathered_view, self.world, self._gathered_view.shape[1], eng.k0_grad,
-                                  eng.k0_touched[eng.touch_par])
+            rows = self._gathered_view.shape[1]
+            if getattr(eng, 'deterministic_scatter', False):      # replicas stay bit-identical: every rank adds in (rank, sample) order
+                ops.k0_scatter_packed_sorted(eng.cfg.pp, self._gathered_view, self.world, rows, eng.k0_grad,
+                                             eng.scatter_work(self.world * rows), eng.k0_touched[eng.touch_par])
+            else:
+                ops.k0_scatter_packed(eng.cfg.pp, self._gathered_view, self.world, rows, eng.k0_grad, eng.k0_touched[eng.touch_par])
             eng.x_slab = (0, X)
             self.all_reduce_small([eng.flat.grad, eng.se3_grad], async_op=True)     # finished by wait_small() after the grid pass
             eng.grad_scale = 1.0 / self.world

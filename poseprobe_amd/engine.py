@@ -274,8 +274,13 @@ class TrainEngine:
 
     def __init__(self, cfg: SceneConfig, n_views, H, W, n_rand, device='cuda', lr_pose=1e-3, lr_pose_end=1e-4,
                  pose_iters=1, lrate_decay=10, loss_scale=0.1, weight_main=1.0, weight_tv_k0=0.01, weight_mask=0.1,
-                 fix_first=True, capacity=None, x_slab=None, dist_ctx=None):
+                 fix_first=True, capacity=None, x_slab=None, dist_ctx=None, deterministic_scatter=False):
+        """deterministic_scatter: the k0 gradient is accumulated per voxel in sample order (sorted scatter, ~0.15 ms instead of
+        0.02 ms per step) instead of by float atomics - bit-identical gradient grids for identical inputs, and bit-identical
+        replicas in the multi-GPU "samples" mode without the periodic re-broadcast."""
         self.cfg, self.dev = cfg, torch.device(device)
+        self.deterministic_scatter = bool(deterministic_scatter)
+        self._scatter_work = None
         self.V, self.H, self.W, self.N = n_views, H, W, n_rand
         cap = capacity or n_rand * cfg.n_samples
         self.ws = Workspace(n_rand, cap, self.dev)
@@ -358,6 +363,13 @@ class TrainEngine:
         return t.permute(3, 0, 1, 2)[None]
 
     # ---- one step -------------------------------------------------------------------------------------------
+    def scatter_work(self, n_samples):
+        """Workspace of the deterministic scatter (grown on demand, kept)."""
+        need = ops.k0_scatter_sorted_workspace(n_samples)
+        if self._scatter_work is None or self._scatter_work.numel() < need:
+            self._scatter_work = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        return self._scatter_work
+
     def zero_grads(self):
         self.k0_grad.zero_()
         self.k0_touched.zero_()
@@ -401,7 +413,10 @@ class TrainEngine:
 
         def after_k0():
             if self.dist is None:
-                ops.k0_scatter_samples(sc, ws.pts, ws.count, ws.cap, ws.g_feat, self.k0_grad, touched)
+                if self.deterministic_scatter:
+                    ops.k0_scatter_samples_sorted(sc, ws.pts, ws.count, ws.cap, ws.g_feat, self.k0_grad, self.scatter_work(ws.cap), touched)
+                else:
+                    ops.k0_scatter_samples(sc, ws.pts, ws.count, ws.cap, ws.g_feat, self.k0_grad, touched)
             else:
                 self.dist.start_grid_reduce(self)
         self.core.backward(ws, self.k0_cl, self.sdf, P.view('sdf_ab'), P.view('rgbnet'), P.view('warp'), inv_s, self.pe_w,

@@ -182,6 +182,24 @@ def k0_scatter_samples(sc, pts, count, capacity, feat_grad, k0_grad_cl, touched=
               _u8(touched), _stream())
 
 
+def k0_scatter_sorted_workspace(n_samples):
+    """Bytes of device workspace the deterministic scatters need for n_samples = n_shards * capacity samples."""
+    b = ctypes.c_int64()
+    _lib.call('pp_k0_scatter_sorted_workspace', int(n_samples), ctypes.byref(b))
+    return b.value
+
+
+def k0_scatter_samples_sorted(sc, pts, count, capacity, feat_grad, k0_grad_cl, work, touched=None):
+    """Deterministic pp_k0_scatter_samples: contributions sorted by voxel and added in sample order (work: uint8 tensor)."""
+    _lib.call('pp_k0_scatter_samples_sorted', ctypes.byref(sc), _f(pts), _i(count), capacity, _f(feat_grad), _f(k0_grad_cl),
+              _u8(touched), _u8(work), int(work.numel()), _stream())
+
+
+def k0_scatter_packed_sorted(sc, packed, n_shards, capacity, k0_grad_cl, work, touched=None):
+    _lib.call('pp_k0_scatter_packed_sorted', ctypes.byref(sc), _f(packed), int(n_shards), capacity, _f(k0_grad_cl), _u8(touched),
+              _u8(work), int(work.numel()), _stream())
+
+
 # ------------------------------------------------------------------------------------------- MLPs
 def rgbnet_fwd(params, feat, count, capacity, acts, rgb):
     _lib.call('pp_rgbnet_fwd', _f(params), _f(feat), _i(count), capacity, _f(acts), _f(rgb), _stream())

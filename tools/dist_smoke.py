@@ -1,7 +1,7 @@
 """Two ranks on ONE GPU (gloo backend, CUDA tensors): runs the real multi-GPU choreography of poseprobe_amd.dist with the HIP
 kernels - pack -> all-gather -> replayed scatter -> replicated optimiser ("samples") or reduce / slab Adam / gather ("zero1")
 - and checks that both replicas end up with the same parameters and that they track a single-process run over the union of
-the rays.   python tools/dist_smoke.py [samples|zero1]"""
+the rays.   python tools/dist_smoke.py [samples|zero1] [det]"""
 import os, sys, socket
 import numpy as np
 import torch
@@ -9,6 +9,9 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+DET = len(sys.argv) > 2 and sys.argv[2] == 'det'      # deterministic (sorted) k0 scatter: replicas bit-identical in "samples" mode
 
 
 def build(N, dctx=None):
@@ -19,7 +22,7 @@ def build(N, dctx=None):
     rs = syn.range_shape()
     cfg = SceneConfig(syn.XYZ_MIN, syn.XYZ_MAX, G ** 3, out_range=float(rs.max()))
     views = syn.make_views(V, H, W)
-    eng = TrainEngine(cfg, V, H, W, N, pose_iters=1000, dist_ctx=dctx)
+    eng = TrainEngine(cfg, V, H, W, N, pose_iters=1000, dist_ctx=dctx, deterministic_scatter=DET)
     eng.set_views(views['images'], views['masks'], views['Ks'], views['w2c'])
     P = reference_like_params(cfg, 3)
     eng.load_reference_params(P['k0'], P['sdf'], P['sdf_alpha'], P['sdf_beta'], P['rgbnet'], P['warp'],
@@ -84,7 +87,7 @@ if __name__ == '__main__':
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, 2, port, mode, q)) for r in range(2)]      # (spawned children re-read sys.argv: DET carries over)
     for p in procs: p.start()
     outs, g_sharded = q.get(timeout=240)
     for p in procs: p.join(60)
@@ -110,6 +113,9 @@ if __name__ == '__main__':
     frac = float(((k0a - k0s).abs() > 1e-3).float().mean())
     print(f'[{mode}] vs single process on the union batch: {frac:.2%} of k0 entries differ by more than 1e-3, '
           f'se3 max diff {float((sa - eng.se3.detach().cpu()).abs().max()):.3e}')
+    if DET and mode == 'samples':
+        print(f'[{mode}] deterministic scatter: replicas bit-identical: {bool(torch.equal(k0a, k0b))}')
+        grads_ok = grads_ok and bool(torch.equal(k0a, k0b))
     ok = grads_ok and float((k0a - k0b).abs().max()) < 1e-4 and float((fa - fb).abs().max()) < 1e-4 and frac < 0.02
     print('OK' if ok else 'MISMATCH')
     sys.exit(0 if ok else 1)
