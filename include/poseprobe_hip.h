@@ -188,7 +188,7 @@ int pp_k0_scatter_samples(const pp_scene* sc, const float* pts, const int32_t* c
 
 /* Deterministic variants of the two scatters above: the (sample, corner) contributions are sorted by voxel (stable radix sort) and
  * added per voxel in ascending (shard, sample, corner) order - bit-identical results for identical inputs, from run to run and
- * between ranks that replay the same shards (float atomics retire in hardware order).  About 7 x the time of the atomic kernels:
+ * between ranks that replay the same shards (float atomics retire in hardware order).  About 6 x the time of the atomic kernels:
  * an option.  `work`: device memory of pp_k0_scatter_sorted_workspace(n_shards * capacity) bytes; grids up to 2^32 - 2 voxels. */
 int pp_k0_scatter_sorted_workspace(int64_t n_samples, int64_t* bytes);
 int pp_k0_scatter_samples_sorted(const pp_scene* sc, const float* pts, const int32_t* count, int32_t capacity,

@@ -275,8 +275,8 @@ class TrainEngine:
     def __init__(self, cfg: SceneConfig, n_views, H, W, n_rand, device='cuda', lr_pose=1e-3, lr_pose_end=1e-4,
                  pose_iters=1, lrate_decay=10, loss_scale=0.1, weight_main=1.0, weight_tv_k0=0.01, weight_mask=0.1,
                  fix_first=True, capacity=None, x_slab=None, dist_ctx=None, deterministic_scatter=False):
-        """deterministic_scatter: the k0 gradient is accumulated per voxel in sample order (sorted scatter, ~0.15 ms instead of
-        0.02 ms per step) instead of by float atomics - bit-identical gradient grids for identical inputs, and bit-identical
+        """deterministic_scatter: the k0 gradient is accumulated per voxel in sample order (sorted scatter, ~0.2 ms instead of
+        0.04 ms per step) instead of by float atomics - bit-identical gradient grids for identical inputs, and bit-identical
         replicas in the multi-GPU "samples" mode without the periodic re-broadcast."""
         self.cfg, self.dev = cfg, torch.device(device)
         self.deterministic_scatter = bool(deterministic_scatter)
