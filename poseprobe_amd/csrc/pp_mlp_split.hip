@@ -70,13 +70,22 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
-// block-wide maximum of a non-negative value (prologue only)
-__device__ __forceinline__ float block_max(float v, float* red, int tid) {
-  v = wave_max(v);
+// block-wide maximum of a non-negative value (prologues): DPP row maxima, sixteen partials through LDS, ONE barrier per call - the
+// calls alternate between two slot sets (`red`: [2][16] floats, `phase` counts the calls), so the readers of one call are done
+// with their set before the call after the next writes it again
+__device__ __forceinline__ float block_max(float v, float* red, int tid, int& phase) {
+  float* set = red + 16 * (phase & 1);
+  ++phase;
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true)));
+  if ((tid & 15) == 0) set[tid >> 4] = v;
   __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float4 a = *reinterpret_cast<const float4*>(set), b = *reinterpret_cast<const float4*>(set + 4),
+               c = *reinterpret_cast<const float4*>(set + 8), d = *reinterpret_cast<const float4*>(set + 12);
+  return fmaxf(fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))),
+               fmaxf(fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w)), fmaxf(fmaxf(d.x, d.y), fmaxf(d.z, d.w))));
 }
 // exponent e of the power of two with mx * 2^e in [2^14, 2^15), clamped to +-60 so that products of two scales stay finite;
 // scales are kept as exponents: reciprocals and products are integer arithmetic + one v_ldexp_f32
@@ -106,7 +115,7 @@ __device__ __forceinline__ float asum4(const float4& v) { return (fabsf(v.x) + f
 
 // forward weights of feature n: k = 16 ks + 8 lh + j.  Returns the exponent of the layer's scale; l1 = max_n sum_k |W[n][k]|.
 __device__ __forceinline__ int load_w_rows_split(SplitW& w, float& l1, const float* __restrict__ W, int n, int lh, float* red,
-                                                   int tid) {
+                                                   int tid, int& phase) {
   float4 v[16];
   float mx = 0.f, sum = 0.f;
 #pragma unroll
@@ -117,9 +126,9 @@ __device__ __forceinline__ int load_w_rows_split(SplitW& w, float& l1, const flo
     sum += asum4(v[2 * ks]) + asum4(v[2 * ks + 1]);
   }
   sum += __shfl_xor(sum, 32, 64);
-  const int e = scale_exp(block_max(mx, red, tid));
+  const int e = scale_exp(block_max(mx, red, tid, phase));
   const float s = pow2(e);
-  l1 = block_max(sum, red, tid) * 1.0001f;
+  l1 = block_max(sum, red, tid, phase) * 1.0001f;
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) split8(v[2 * ks], v[2 * ks + 1], s, w.h[ks], w.l[ks]);
   return e;
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(256) void k_warp_fused_fwd_s(const float* __restric
   __shared__ __attribute__((aligned(16))) float Red[4 * 64 * 4];
   __shared__ float Ps[2][52];                                              // 48 coordinates + max |.| of each 16 at [48..50]
   __shared__ unsigned Mx[2][8];                                            // maxima of (X0, X1, X2) x (half 0, half 1), two parities
-  __shared__ float red4[4];
+  __shared__ __attribute__((aligned(16))) float red4[32];
   __shared__ __attribute__((aligned(16))) float Bs[4][128];                // hidden-layer biases, row 3 = zeros
   static_assert(2 * PLANE * 2 >= TILE_ROWS * LDA * 4, "fp32 view must fit into a split tile");
   const int M = min(count[0], capacity);
@@ -306,21 +315,22 @@ __global__ __launch_bounds__(256) void k_warp_fused_fwd_s(const float* __restric
   const size_t LS = (size_t)capacity * 4 * 128;
 
   SplitW w1, w2, w3;
+  int phase = 0;                        // call counter of block_max
   float l1_1, l1_2, l1_3;
-  const int ew1 = load_w_rows_split(w1, l1_1, params + WPF_W1, col, lh, red4, tid);
-  const int ew2 = load_w_rows_split(w2, l1_2, params + WPF_W2, col, lh, red4, tid);
-  const int ew3 = load_w_rows_split(w3, l1_3, params + WPF_W3, col, lh, red4, tid);
+  const int ew1 = load_w_rows_split(w1, l1_1, params + WPF_W1, col, lh, red4, tid, phase);
+  const int ew2 = load_w_rows_split(w2, l1_2, params + WPF_W2, col, lh, red4, tid, phase);
+  const int ew3 = load_w_rows_split(w3, l1_3, params + WPF_W3, col, lh, red4, tid, phase);
   // biases of the hidden layers in LDS: row l = the layer's biases, row 3 = zeros (tangent lanes, and the input layer whose
   // bias rides in the product); a lane reads its four runs of four from `brow(l)`
   if (tid < 128) { Bs[0][tid] = params[WPF_B1 + tid]; Bs[1][tid] = params[WPF_B2 + tid]; Bs[2][tid] = params[WPF_B3 + tid]; Bs[3][tid] = 0.f; }
   auto brow = [&](int l) -> const float* { return &Bs[primal ? l : 3][fb]; };
-  const float b1mx = block_max(fabsf(params[WPF_B1 + col]), red4, tid), b2mx = block_max(fabsf(params[WPF_B2 + col]), red4, tid);
+  const float b1mx = block_max(fabsf(params[WPF_B1 + col]), red4, tid, phase), b2mx = block_max(fabsf(params[WPF_B2 + col]), red4, tid, phase);
   // input layer as a K = 16 product: A = [w0x w0y w0z b0 0 ...] (lanes lh = 0), B = [px py pz 1 0 ...] / unit tangents
   const float w0x = params[WPF_W0 + col * 3], w0y = params[WPF_W0 + col * 3 + 1], w0z = params[WPF_W0 + col * 3 + 2];
   const float b0 = params[WPF_B0 + col];
-  const float w0l1 = block_max((fabsf(w0x) + fabsf(w0y)) + fabsf(w0z), red4, tid) * 1.0001f;
-  const float w0mx = block_max(fmaxf(fmaxf(fabsf(w0x), fabsf(w0y)), fabsf(w0z)), red4, tid);
-  const float b0mx = block_max(fabsf(b0), red4, tid);
+  const float w0l1 = block_max((fabsf(w0x) + fabsf(w0y)) + fabsf(w0z), red4, tid, phase) * 1.0001f;
+  const float w0mx = block_max(fmaxf(fmaxf(fabsf(w0x), fabsf(w0y)), fabsf(w0z)), red4, tid, phase);
+  const float b0mx = block_max(fabsf(b0), red4, tid, phase);
   const int ew0 = scale_exp(fmaxf(w0mx, b0mx));
   pp_half8 a0h, a0l;
   {
@@ -508,7 +518,7 @@ namespace {
 
 // transposed weights of input feature j (A operand of the data-gradient product): k = n = 16 ks + 8 lh + jj, value W[n][j].
 // Returns the exponent of the layer's scale; l1 = max_j sum_n |W[n][j]|.
-__device__ __forceinline__ int load_w_cols_split(SplitW& w, float& l1, const float* __restrict__ W, int j, int lh, float* red, int tid) {
+__device__ __forceinline__ int load_w_cols_split(SplitW& w, float& l1, const float* __restrict__ W, int j, int lh, float* red, int tid, int& phase) {
   float4 v[16];
   float mx = 0.f, sum = 0.f;
 #pragma unroll
@@ -520,9 +530,9 @@ __device__ __forceinline__ int load_w_cols_split(SplitW& w, float& l1, const flo
     sum += asum4(v[2 * ks]) + asum4(v[2 * ks + 1]);
   }
   sum += __shfl_xor(sum, 32, 64);
-  const int e = scale_exp(block_max(mx, red, tid));
+  const int e = scale_exp(block_max(mx, red, tid, phase));
   const float s = pow2(e);
-  l1 = block_max(sum, red, tid) * 1.0001f;
+  l1 = block_max(sum, red, tid, phase) * 1.0001f;
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) split8(v[2 * ks], v[2 * ks + 1], s, w.h[ks], w.l[ks]);
   return e;
@@ -624,7 +634,7 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd_s(const float* __restric
   __shared__ __attribute__((aligned(16))) float Ps[2][64];                // sample positions of the current / next tile
   __shared__ __attribute__((aligned(16))) float Red[4 * 64];
   __shared__ unsigned Mx[2][8];      // per parity: max |Ybar3| (halves 0, 1), |Ybar2| (0, 1), |Ybar1| (0, 1), max |out_grad| of the tile
-  __shared__ float red4[4];
+  __shared__ __attribute__((aligned(16))) float red4[32];
   const int M = min(count[0], capacity);
   const int R = 4 * M;
   const int ntiles = (M + 15) >> 4;
@@ -641,16 +651,17 @@ __global__ __launch_bounds__(256) void k_warp_fused_bwd_s(const float* __restric
   const float* __restrict__ X3 = acts + 3 * LS;
 
   SplitW w3, w2, w1;
+  int phase = 0;                        // call counter of block_max
   float l1_3, l1_2, l1_1;
-  const int ew3 = load_w_cols_split(w3, l1_3, params + WPF_W3, col, lh, red4, tid);
-  const int ew2 = load_w_cols_split(w2, l1_2, params + WPF_W2, col, lh, red4, tid);
-  const int ew1 = load_w_cols_split(w1, l1_1, params + WPF_W1, col, lh, red4, tid);
+  const int ew3 = load_w_cols_split(w3, l1_3, params + WPF_W3, col, lh, red4, tid, phase);
+  const int ew2 = load_w_cols_split(w2, l1_2, params + WPF_W2, col, lh, red4, tid, phase);
+  const int ew1 = load_w_cols_split(w1, l1_1, params + WPF_W1, col, lh, red4, tid, phase);
   // output layer backward as a K = 16 product: A = [w4_0 w4_1 w4_2 w4_3 0 ...] * out_range of feature `col` (lanes lh = 0),
   // B = the row's four out_grad entries
   const float w4a = params[WPF_W4 + col] * out_range, w4b = params[WPF_W4 + 128 + col] * out_range,
               w4c = params[WPF_W4 + 256 + col] * out_range, w4d = params[WPF_W4 + 384 + col] * out_range;
-  const float w4l1 = block_max((fabsf(w4a) + fabsf(w4b)) + (fabsf(w4c) + fabsf(w4d)), red4, tid) * 1.0001f;
-  const int ew4 = scale_exp(block_max(fmaxf(fmaxf(fabsf(w4a), fabsf(w4b)), fmaxf(fabsf(w4c), fabsf(w4d))), red4, tid));
+  const float w4l1 = block_max((fabsf(w4a) + fabsf(w4b)) + (fabsf(w4c) + fabsf(w4d)), red4, tid, phase) * 1.0001f;
+  const int ew4 = scale_exp(block_max(fmaxf(fmaxf(fabsf(w4a), fabsf(w4b)), fmaxf(fabsf(w4c), fabsf(w4d))), red4, tid, phase));
   pp_half8 a4h, a4l;
   {
     const float z = 0.f;
@@ -912,7 +923,7 @@ namespace {
 #define FPL (TILE_ROWS * FLD)
 
 // forward weights of feature n of the 64-wide input layer: k = 16 ks + 8 lh + j, ks < 4 (the upper half of `w` stays unused)
-__device__ __forceinline__ int load_w0_rows_split(SplitW& w, float& l1, const float* __restrict__ W, int n, int lh, float* red, int tid) {
+__device__ __forceinline__ int load_w0_rows_split(SplitW& w, float& l1, const float* __restrict__ W, int n, int lh, float* red, int tid, int& phase) {
   float4 v[8];
   float mx = 0.f, sum = 0.f;
 #pragma unroll
@@ -923,9 +934,9 @@ __device__ __forceinline__ int load_w0_rows_split(SplitW& w, float& l1, const fl
     sum += asum4(v[2 * ks]) + asum4(v[2 * ks + 1]);
   }
   sum += __shfl_xor(sum, 32, 64);
-  const int e = scale_exp(block_max(mx, red, tid));
+  const int e = scale_exp(block_max(mx, red, tid, phase));
   const float s = pow2(e);
-  l1 = block_max(sum, red, tid) * 1.0001f;
+  l1 = block_max(sum, red, tid, phase) * 1.0001f;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) split8(v[2 * ks], v[2 * ks + 1], s, w.h[ks], w.l[ks]);
 #pragma unroll
@@ -958,7 +969,7 @@ __global__ __launch_bounds__(256) void k_rgb_fused_fwd_s(const float* __restrict
   __shared__ __attribute__((aligned(16))) float Bs[3][128];
   __shared__ int Er[TILE_ROWS];                                            // scale exponent of every row of the feature tile
   __shared__ unsigned Mx[2][8];      // per parity: max |feat| (halves 0, 1), |H0| (0, 1), |H1| (0, 1)
-  __shared__ float red4[4];
+  __shared__ __attribute__((aligned(16))) float red4[32];
   const int R = min(count[0], capacity);
   const int ntiles = (R + TILE_ROWS - 1) / TILE_ROWS;
   if ((int)blockIdx.x >= ntiles) return;
@@ -969,12 +980,13 @@ __global__ __launch_bounds__(256) void k_rgb_fused_fwd_s(const float* __restrict
   const size_t LS = (size_t)capacity * 128;
 
   SplitW w0, w1, w2;
+  int phase = 0;                        // call counter of block_max
   float l1_0, l1_1, l1_2;
-  const int ew0 = load_w0_rows_split(w0, l1_0, params + RGF_W0, col, lh, red4, tid);
-  const int ew1 = load_w_rows_split(w1, l1_1, params + RGF_W1, col, lh, red4, tid);
-  const int ew2 = load_w_rows_split(w2, l1_2, params + RGF_W2, col, lh, red4, tid);
+  const int ew0 = load_w0_rows_split(w0, l1_0, params + RGF_W0, col, lh, red4, tid, phase);
+  const int ew1 = load_w_rows_split(w1, l1_1, params + RGF_W1, col, lh, red4, tid, phase);
+  const int ew2 = load_w_rows_split(w2, l1_2, params + RGF_W2, col, lh, red4, tid, phase);
   if (tid < 128) { Bs[0][tid] = params[RGF_B0 + tid]; Bs[1][tid] = params[RGF_B1 + tid]; Bs[2][tid] = params[RGF_B2 + tid]; }
-  const float b0mx = block_max(fabsf(params[RGF_B0 + col]), red4, tid), b1mx = block_max(fabsf(params[RGF_B1 + col]), red4, tid);
+  const float b0mx = block_max(fabsf(params[RGF_B0 + col]), red4, tid, phase), b1mx = block_max(fabsf(params[RGF_B1 + col]), red4, tid, phase);
   for (int i = tid; i < 512; i += 256) {
     const int r = i >> 7, j = i & 127;
     W3s[r * LDA + j] = (r < 3) ? params[RGF_W3 + r * 128 + j] : 0.f;
@@ -1120,7 +1132,7 @@ __global__ __launch_bounds__(256) void k_rgb_fused_bwd_s(const float* __restrict
   __shared__ __attribute__((aligned(16))) float RG[2][2][192];            // [parity][rgb | rgb_grad] of a tile
   __shared__ __attribute__((aligned(16))) float GL[TILE_ROWS * 4];        // d loss / d logits of the staged tile
   __shared__ unsigned Mx[2][8];      // per parity: max |Ybar2| (halves 0, 1), |Ybar1| (0, 1), max |d logits| of the tile
-  __shared__ float red4[4];
+  __shared__ __attribute__((aligned(16))) float red4[32];
   const int R = min(count[0], capacity);
   const int ntiles = (R + TILE_ROWS - 1) / TILE_ROWS;
   if ((int)blockIdx.x >= ntiles) return;
@@ -1134,9 +1146,10 @@ __global__ __launch_bounds__(256) void k_rgb_fused_bwd_s(const float* __restrict
   const float* __restrict__ H2 = acts + 2 * LS;
 
   SplitW w2, w1, w0;
+  int phase = 0;                        // call counter of block_max
   float l1_2, l1_1, l1_dummy;
-  const int ew2 = load_w_cols_split(w2, l1_2, params + RGF_W2, col, lh, red4, tid);
-  const int ew1 = load_w_cols_split(w1, l1_1, params + RGF_W1, col, lh, red4, tid);
+  const int ew2 = load_w_cols_split(w2, l1_2, params + RGF_W2, col, lh, red4, tid, phase);
+  const int ew1 = load_w_cols_split(w1, l1_1, params + RGF_W1, col, lh, red4, tid, phase);
   // last product: feat_grad[64 rows][64] = Ybar0 . W0, wavefront = (row half wid >> 1, feature block wid & 1); A operand =
   // transposed W0 (k = hidden feature, value W0[k][f]) of input feature f = 32 (wid & 1) + l31
   const int rb = wid >> 1, fcol = (wid & 1) * 32 + l31;
@@ -1151,7 +1164,7 @@ __global__ __launch_bounds__(256) void k_rgb_fused_bwd_s(const float* __restrict
       v[2 * ks + 1] = make_float4(p[256], p[320], p[384], p[448]);
       mx = fmaxf(mx, fmaxf(amax4(v[2 * ks]), amax4(v[2 * ks + 1])));
     }
-    ew0 = scale_exp(block_max(mx, red4, tid));
+    ew0 = scale_exp(block_max(mx, red4, tid, phase));
     const float s = pow2(ew0);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) split8(v[2 * ks], v[2 * ks + 1], s, w0.h[ks], w0.l[ks]);
@@ -1159,8 +1172,8 @@ __global__ __launch_bounds__(256) void k_rgb_fused_bwd_s(const float* __restrict
   }
   // output layer backward as a K = 16 product: A = [w3_0 w3_1 w3_2 0 ...] of feature `col` (lanes lh = 0), B = d loss / d logits
   const float w3a = params[RGF_W3 + col], w3b = params[RGF_W3 + 128 + col], w3c = params[RGF_W3 + 256 + col];
-  const float w3l1 = block_max((fabsf(w3a) + fabsf(w3b)) + fabsf(w3c), red4, tid) * 1.0001f;
-  const int ew3 = scale_exp(block_max(fmaxf(fmaxf(fabsf(w3a), fabsf(w3b)), fabsf(w3c)), red4, tid));
+  const float w3l1 = block_max((fabsf(w3a) + fabsf(w3b)) + fabsf(w3c), red4, tid, phase) * 1.0001f;
+  const int ew3 = scale_exp(block_max(fmaxf(fmaxf(fabsf(w3a), fabsf(w3b)), fabsf(w3c)), red4, tid, phase));
   pp_half8 a3h, a3l;
   {
     const float z = 0.f;
