@@ -18,6 +18,8 @@ Prints ONE JSON line on rank 0 (driver contract).  Objects besides the contract'
   dual_branch       BASELINE config 2 as the reference runs it: object step + scene branch (bg_nerf) sharing the poses;
                     its rays/s and ms/step are repeated as top-level fields `dual_branch_rays_per_s`, `dual_branch_ms_per_step`
   roofline_scene    the scene branch's forward + backward GEMM chains against the fp16 MFMA pipe they issue on
+  fp32_instructions the same timed loop with every MLP product on the fp32 MFMA instructions (option mlp_split = 0); `arithmetic`
+                    states what the default path computes
   inference         whole-view inference as the reference evaluates (lib/nvs_fun.py: 4096-ray chunks of Voxurf.inference): rays/s
   cpu_baseline      the oracle (CPU restatement, "port") timed on this host's cores for a bounded sample (N=1, rank 0)
   psnr_parity       oracle and HIP engine trained from one initialisation with the same per-step rays and jitter; PSNR of
@@ -556,13 +558,35 @@ def main():
     Mx = int(eng.ws.count.item())
     for n, f in originals.items():
         setattr(ops, n, f)
+
+    # the same step with every matrix product on the fp32 instructions (option mlp_split = 0): reported beside `value` so that
+    # both arithmetic paths of the MLP kernels are on the record (same engine, the same pre-generated rays reused)
+    from poseprobe_amd import _lib
+    split_default = _lib.get_option('mlp_split')
+    fp32_path = None
+    if split_default and _lib.get_option('mlp_fused'):
+        _lib.set_option('mlp_split', 0)
+        for s in range(args.warmup):
+            eng.train_step(idx_all[s], jit_all[s], gs + total + extra + s)
+        barrier()
+        t1 = time.perf_counter()
+        for s in range(args.warmup, total):
+            eng.train_step(idx_all[s], jit_all[s], gs + total + extra + s)
+        barrier()
+        dt32 = time.perf_counter() - t1
+        if use_dist:
+            t = torch.tensor([dt32], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt32 = float(t.item())
+        _lib.set_option('mlp_split', split_default)
+        fp32_path = {'value': N * world * args.steps / dt32, 'unit': 'rays/s', 'ms_per_step': dt32 / args.steps * 1e3,
+                     'what': 'the same timed loop with option mlp_split = 0: all MLP products on v_mfma_f32_32x32x2_f32'}
     hidden = 2 * 128 * 128
     flops = {'k_warp_fused_fwd': 3 * 4 * hidden, 'k_warp_fused_bwd': 3 * 4 * hidden, 'k_wgrad_chain<128> (warp)': 3 * 4 * hidden,
              'k_rgb_fused_fwd': 2 * (64 * 128 + 2 * 128 * 128), 'k_rgb_fused_bwd': 2 * (64 * 128 + 2 * 128 * 128),
              'k_wgrad_chain<64> (rgbnet)': 2 * (64 * 128 + 2 * 128 * 128)}          # MFMA-shaped FLOP per sample
     # which kernels run their 128 x 128 products as three fp16 MFMA products per fp32 product (option mlp_split, pp_mlp_split.hip):
     # those are priced against the fp16 pipe with the FLOPs they actually issue (3 x), the others against the fp32 instructions
-    from poseprobe_amd import _lib
     split_bits = _lib.get_option('mlp_split') if _lib.get_option('mlp_fused') else 0
     split_of = {'k_warp_fused_fwd': split_bits & 1, 'k_warp_fused_bwd': split_bits & 2, 'k_rgb_fused_fwd': split_bits & 4,
                 'k_rgb_fused_bwd': split_bits & 8, 'k_wgrad_chain<128> (warp)': split_bits & 16, 'k_wgrad_chain<64> (rgbnet)': split_bits & 16}
@@ -621,6 +645,14 @@ def main():
             'metric': 'rays_per_sec_train_step', 'value': N * world * args.steps / dt, 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'arithmetic': ('fp32 operands, accumulation and results everywhere; ' +
+                           ('the 128 x 128 products of the two MLPs are evaluated as three fp16 MFMA products per fp32 product '
+                            '(operands split into 11 + 11 significant bits with a power-of-two scale, fp32 accumulation): measured error '
+                            'against fp64 equal to the fp32 MFMA instructions\' (3.4e-8 rms on the warp outputs for both, 4.5-6.8e-7 vs '
+                            '5.2-7.5e-7 relative on the weight gradients; tools/dbg/mlp_split_err.py, wgrad_err.py); `fp32_instructions` '
+                            'is the same step with those products on v_mfma_f32_32x32x2_f32' if split_bits else
+                            'all MLP products on v_mfma_f32_32x32x2_f32')),
+            'fp32_instructions': fp32_path,
             'config': {'workload': f'DTU-scan1-like {V}-view {H}x{W}, object-branch train step (ray select, render, '
                                    f'losses, backward, TV+Adam), {G}^3 grid, {cfg.n_samples} samples/ray, '
                                    f'N_rand={N}/GPU; per-step ray permutation + jitter pre-generated on the host and resident '
