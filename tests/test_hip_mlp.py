@@ -145,3 +145,61 @@ def test_rgbnet_chain_matches_torch(M, cap):
         assert_close(c(gb), c(b.grad), rtol=1e-3, atol=2e-5, name=f'rgb b{i} grad', scaled=1e-3)
     # the zero padding of the 57 -> 64 input columns receives no gradient from real data (features there are zero)
     assert float(pgrad[:128 * 64].view(128, 64)[:, 57:].abs().max()) == 0
+
+
+def test_split_precision_kernels_are_as_accurate_as_the_fp32_instructions():
+    """The default MLP kernels evaluate every 128 x 128 product as three fp16 MFMA products per fp32 product (option mlp_split).
+    Against a float64 evaluation of the same network on the same inputs their error must not exceed the fp32-instruction
+    kernels' (mlp_split = 0) by more than a quarter - for the warp outputs (values and Jacobians), the rgb outputs and the
+    weight gradients, with O(1) weights and with weights / gradients scaled down by 1e-3 / 1e-6 (small magnitudes are where a
+    fixed-range 16-bit format would lose)."""
+    from poseprobe_amd import ops, _lib
+    from poseprobe_amd.engine import pack_rgbnet
+    dev = 'cuda'
+    M = cap = 20000
+    count = torch.tensor([M], dtype=torch.int32, device=dev)
+    default = _lib.get_option('mlp_split')
+    try:
+        for wscale, gscale in ((1.0, 1.0), (1e-3, 1e-6)):
+            g = torch.Generator().manual_seed(17)
+            layers = [(W * (wscale if 0 < i < 4 else 1.0), b * wscale) for i, (W, b) in enumerate(_warp_params(3))]
+            pts_h = torch.randn(cap, 3, generator=g) * 0.5
+            ref = _warp_ref([(W.double(), b.double()) for W, b in layers], pts_h.double()).reshape(M, 16)
+            P = _pack(layers)
+            params = torch.zeros(P.numel() + 60, device=dev); params[:P.numel()] = P.to(dev)
+            og = (torch.randn(cap, 16, generator=g) * gscale * torch.exp(torch.randn(cap, 1, generator=g) * 2)).to(dev)
+            rl = [(W * (wscale if i < 3 else 1.0), b * wscale) for i, (W, b) in enumerate(_rgb_params(5))]
+            feat_h = torch.zeros(cap, 64); feat_h[:, :57] = torch.randn(cap, 57, generator=g)
+            h = feat_h[:, :57].double()
+            for li, (W, b) in enumerate(rl):
+                h = h @ W.double().T + b.double()
+                h = torch.relu(h) if li < 3 else torch.sigmoid(h)
+            rp = pack_rgbnet(rl)
+            rparams = torch.zeros(rp.numel() + 60, device=dev); rparams[:rp.numel()] = rp.to(dev)
+            err = {}
+            for mode in (0, default):
+                _lib.set_option('mlp_split', mode)
+                acts = torch.zeros(4 * cap * 4 * 128, device=dev); out = torch.zeros(cap, 16, device=dev)
+                ops.warp_fwd(params, pts_h.to(dev), count, cap, OUT_RANGE, acts, out)
+                e = (out.cpu().double() - ref).abs()
+                keep = ~(e > 1e-3 * ref.abs().max()).any(1)                     # samples with a flipped ReLU are not rounding error
+                racts = torch.zeros(3 * cap * 128, device=dev); rgb = torch.zeros(cap, 3, device=dev)
+                ops.rgbnet_fwd(rparams, feat_h.to(dev), count, cap, racts, rgb)
+                # weight gradients against float64 products of THIS mode's own Ybar and X (isolates the weight-gradient kernel)
+                scratch = torch.zeros(3 * cap * 4 * 128 + 49152, device=dev)
+                wg = torch.zeros_like(params); pg = torch.zeros(cap, 3, device=dev)
+                ops.warp_bwd_data(params, pts_h.to(dev), acts, og, count, cap, OUT_RANGE, scratch, wg, pg)
+                wg.zero_()
+                ops.warp_bwd_weights(acts, scratch, count, cap, wg)
+                torch.cuda.synchronize()
+                X = acts.view(4, cap * 4, 128)[:, :4 * M].double().cpu()
+                Y = scratch[:3 * cap * 4 * 128].view(3, cap * 4, 128)[:, :4 * M].double().cpu()
+                o3 = 128 * 3 + 128 + 2 * (128 * 128 + 128)
+                w3 = wg[o3:o3 + 128 * 128].view(128, 128).double().cpu()
+                r3 = Y[0].T @ X[2]
+                err[mode] = (float((e[keep] ** 2).mean().sqrt()), float(((rgb.cpu().double() - h) ** 2).mean().sqrt()),
+                             float(((w3 - r3) ** 2).mean().sqrt() / (r3 ** 2).mean().sqrt()))
+            for name, a, b in zip(('warp out', 'rgb', 'W3 gradient'), err[0], err[default]):
+                assert b <= 1.25 * a + 1e-12, f'{name} (weights x {wscale}, gradients x {gscale}): fp32 {a:.3e}, split {b:.3e}'
+    finally:
+        _lib.set_option('mlp_split', default)
