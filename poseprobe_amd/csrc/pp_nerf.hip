@@ -22,6 +22,7 @@
 #include "pp_gemm.h"
 #include "pp_gemm_split.h"
 #include "pp_gemm_planes.h"
+#include "pp_gemm_tn256.h"
 #include "pp_mlp_fused.h"      // pp_fused_wgs(): number of CUs
 
 #define NERF_L3D 10
@@ -550,6 +551,7 @@ static const int NERF_GEMM_WGS_WIDE = 512;   // 128 x 256 tiles: 2 resident per 
 static int nerf_wide_tiles() { return pp_opt(PP_OPT_NERF_BN) == 256; }
 #define NERF_SPLIT (pp_opt(PP_OPT_NERF_SPLIT) == 1)
 #define NERF_SPLIT_TN (pp_opt(PP_OPT_NERF_SPLIT_TN) == 1)
+#define NERF_TN256 (pp_opt(PP_OPT_NERF_TN256) == 1)
 #define NERF_BITMASK (pp_opt(PP_OPT_NERF_BITMASK) == 1)
 //   nerf_planes        256-wide layers on the second-generation kernel (pp_gemm_planes.h: weights pre-split into LDS images once
 //                      per pass, 128 x 256 tile on eight wavefronts); needs nerf_split and nerf_bitmask; 0 = first generation
@@ -605,6 +607,14 @@ static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, i
 
 static void nerf_gemm_tn(hipStream_t st, const float* Y, int ldy, int N, const float* X, int ldx, int Kx, float* Wbar,
                          float* bbar, const int32_t* count, int rows, const float* y_max = nullptr, const float* x_max = nullptr) {
+  if (NERF_SPLIT && NERF_SPLIT_TN && NERF_TN256 && y_max && x_max && N == 256 && Kx >= 256) {
+    // all 256 x 256 outputs of a row range in one work-group (pp_gemm_tn256.h); the 64 skip columns of layer 4 go the old way
+    const int tiles = pp_div_up(rows, TN256_ROWS);
+    const int grid = tiles < pp_fused_wgs() ? tiles : pp_fused_wgs();
+    hipLaunchKernelGGL(k_gemm_tn256, dim3(grid), dim3(512), 0, st, Y, ldy, X, ldx, Wbar, ldx, bbar, count, rows, y_max, x_max);
+    if (Kx > 256) nerf_gemm_tn(st, Y, ldy, N, X + 256, ldx, Kx - 256, Wbar + 256, nullptr, count, rows, y_max, x_max);
+    return;
+  }
   const int blocks = (N / 128) * pp_div_up(Kx, 128);
   dim3 b(256);
   if (NERF_SPLIT && NERF_SPLIT_TN && y_max && x_max) {     // one work-group per CU measured best (3.69 vs 3.85 ms at two)
