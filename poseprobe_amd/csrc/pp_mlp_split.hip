@@ -14,16 +14,16 @@
 // 2^-18 of the largest representable value and an absolute floor of 2^-40 of it below that.
 //
 // LDS image of a tile: hi plane [64][136] halfs, lo plane [64][136] halfs (272-byte rows: the 16 rows of a ds_read_b128
-// lane group start 4 banks apart and cover all 64 banks once; the epilogue's 2-byte stores of 32 consecutive features are
-// conflict-free).
+// lane group start 4 banks apart and cover all 64 banks once).
 //
 // Orientation.  The fp32 kernels compute D = X . W^T with the activations as the MFMA A operand, so a lane ends up with 16
 // ROWS of one feature: one scalar LDS / HBM store per element, ~17 instructions per element in the epilogue - with the matrix
 // time cut to a fifth that is what the kernel then waits for.  Here the roles are swapped: A = weights (feature l31 of the
 // wavefront's 32, k = 16 ks + 8 lh + j; register content as before), B = activations (row l31), D[reg][lane] = out[row l31]
 // [feature 32 w + (reg & 3) + 8 (reg >> 2) + 4 lh]: a lane holds four runs of four CONSECUTIVE features of one row, so the
-// epilogue works on packed pairs (v_pk_fma_f32, v_cvt_pk_f16_f32) and stores 8 bytes per LDS write and 16 bytes per HBM
-// write.  The four rows of a warp sample are the four lanes of a quad; the primal row's ReLU state reaches the tangent rows
+// epilogue converts pairs (v_cvt_pk_f16_f32, v_fma_mixlo / mixhi_f16) and stores 8 bytes per LDS write and 16 bytes per HBM
+// write (NOT v_pk_*_f32 arithmetic: those cost 16 cycles beside MFMAs, tools/mfma_valu_probe.hip - the file is compiled with
+// -fno-slp-vectorize).  The four rows of a warp sample are the four lanes of a quad; the primal row's ReLU state reaches the tangent rows
 // by a quad-broadcast DPP operand.  The input layer (3 -> 128 on [p, 1] / unit tangents) is one more MFMA with K padded to 16.
 //
 // Schedule.  With the matrix time cut to a fifth the epilogues (scale, gate, split, store: ~8 instructions per element) cost
@@ -43,7 +43,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDH2 136                // halfs per row of a split tile
 #define PLANE (TILE_ROWS * LDH2)
 #ifndef MS_DBG
-#define MS_DBG 0      // experiments only: 1 = no MFMAs, 2 = no HBM activation stores, 3 = no LDS writes in the epilogues, 4 = no conversions
+#define MS_DBG 0      // experiments only (forward kernels): 1 = no MFMAs, 2 = no HBM activation stores, 3 = no LDS image writes
 #endif
 #ifdef MS_TIMERS      // phase timers (experiments): wave 0 of every work-group sums s_memtime deltas per phase
 __device__ unsigned long long g_ms_t[16];
@@ -61,9 +61,6 @@ extern "C" int pp_debug_read_timers(unsigned long long* out16, int reset) {
 namespace {
 
 struct SplitW { pp_half8 h[8], l[8]; };      // one layer's share of a lane: 64 registers, as the fp32 layout
-
-template <bool B> struct BoolC { static constexpr bool value = B; };
-#define PP_WITH_FULL(cond, f) do { if (cond) f(BoolC<true>{}); else f(BoolC<false>{}); } while (0)
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -278,15 +275,6 @@ __device__ __forceinline__ void slot_max(unsigned* slot, float v, int lane) {
   }
 }
 __device__ __forceinline__ float slot_get(const unsigned* slot) { return __uint_as_float(*slot); }
-
-// bias of the 16 features a lane holds (fb + 8 q + c); zero unless `keep`
-__device__ __forceinline__ void load_bias16(float (&b)[16], const float* __restrict__ bias, int fb, bool keep) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float4 v = *reinterpret_cast<const float4*>(bias + fb + 8 * q);
-    b[4 * q] = keep ? v.x : 0.f; b[4 * q + 1] = keep ? v.y : 0.f; b[4 * q + 2] = keep ? v.z : 0.f; b[4 * q + 3] = keep ? v.w : 0.f;
-  }
-}
 
 }  // namespace
 
@@ -1147,7 +1135,7 @@ __global__ __launch_bounds__(256) void k_rgb_fused_bwd_s(const float* __restrict
 
   SplitW w2, w1, w0;
   int phase = 0;                        // call counter of block_max
-  float l1_2, l1_1, l1_dummy;
+  float l1_2, l1_1;
   const int ew2 = load_w_cols_split(w2, l1_2, params + RGF_W2, col, lh, red4, tid, phase);
   const int ew1 = load_w_cols_split(w1, l1_1, params + RGF_W1, col, lh, red4, tid, phase);
   // last product: feat_grad[64 rows][64] = Ybar0 . W0, wavefront = (row half wid >> 1, feature block wid & 1); A operand =
@@ -1168,7 +1156,6 @@ __global__ __launch_bounds__(256) void k_rgb_fused_bwd_s(const float* __restrict
     const float s = pow2(ew0);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) split8(v[2 * ks], v[2 * ks + 1], s, w0.h[ks], w0.l[ks]);
-    l1_dummy = 0.f;
   }
   // output layer backward as a K = 16 product: A = [w3_0 w3_1 w3_2 0 ...] of feature `col` (lanes lh = 0), B = d loss / d logits
   const float w3a = params[RGF_W3 + col], w3b = params[RGF_W3 + 128 + col], w3c = params[RGF_W3 + 256 + col];
@@ -1351,7 +1338,6 @@ __global__ __launch_bounds__(256) void k_rgb_fused_bwd_s(const float* __restrict
     for (int o = 0; o < 3; ++o) atomicAdd(&params_grad[RGF_W3 + o * 128 + j0], wacc3[o] + red[o * 128 + j0]);
     if (j0 < 3) atomicAdd(&params_grad[RGF_B3 + j0], bacc3 + red[4 * 128 + j0]);
   }
-  (void)l1_dummy;
 }
 
 int pp_launch_rgb_fused_bwd_s(const float* params, const float* acts, const float* rgb, const float* rgb_grad,
