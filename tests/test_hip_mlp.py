@@ -203,3 +203,49 @@ def test_split_precision_kernels_are_as_accurate_as_the_fp32_instructions():
                 assert b <= 1.25 * a + 1e-12, f'{name} (weights x {wscale}, gradients x {gscale}): fp32 {a:.3e}, split {b:.3e}'
     finally:
         _lib.set_option('mlp_split', default)
+
+
+def test_weight_gradient_kernels_follow_growing_magnitudes():
+    """k_wgrad_chain_s keeps ONE running power-of-two scale per operand and wavefront over its whole row range and rescales its
+    accumulators whenever a 16-row group exceeds it.  Synthetic operands whose magnitude grows by 2^40 along the rows (in the
+    order the kernel walks them: from the END of the range) force dozens of rescales per wavefront; small rows in between must
+    not be lost either.  Against float64 products the split kernel may not be worse than the fp32-instruction chain kernel by
+    more than a quarter; the bias column sums (primal rows) ride along."""
+    from poseprobe_amd import ops, _lib
+    dev = 'cuda'
+    M = cap = 6000
+    R = 4 * M
+    count = torch.tensor([M], dtype=torch.int32, device=dev)
+    g = torch.Generator().manual_seed(31)
+    ramp = torch.exp2(torch.linspace(20, -20, R)).unsqueeze(1)                  # rows near the end are the small ones ...
+    ramp[torch.randperm(R, generator=g)[:R // 7]] *= 2.0 ** -12                   # ... and every seventh row is tiny where it sits
+    acts = torch.zeros(4, cap * 4, 128); scratch = torch.zeros(3 * cap * 4 * 128 + 49152)
+    Y = torch.randn(3, R, 128, generator=g) * ramp
+    X = torch.relu(torch.randn(3, R, 128, generator=g)) * torch.exp2(torch.randn(1, R, 1, generator=g) * 4)
+    acts[:3, :R] = X
+    scratch[:3 * cap * 4 * 128].view(3, cap * 4, 128)[:, :R] = Y
+    acts_d, scratch_d = acts.reshape(-1).to(dev), scratch.to(dev)
+    # layers: (Ybar3 = Y[0], X2) -> W3, (Y[1], X1) -> W2, (Y[2], X0) -> W1 ; bias b_l = column sums of Ybar_l over the primal rows
+    base = 128 * 3 + 128
+    off = {1: base, 2: base + 128 * 128 + 128, 3: base + 2 * (128 * 128 + 128)}
+    ref = {3: Y[0].double().T @ X[2].double(), 2: Y[1].double().T @ X[1].double(), 1: Y[2].double().T @ X[0].double()}
+    refb = {3: Y[0][::4].double().sum(0), 2: Y[1][::4].double().sum(0), 1: Y[2][::4].double().sum(0)}
+    default = _lib.get_option('mlp_split')
+    err = {}
+    try:
+        for mode in (default & ~16, default | 16):
+            _lib.set_option('mlp_split', mode | 2)                      # bit 2: the data-gradient kernel leaves b1..b3 to this one
+            wg = torch.zeros(50564 + 60, device=dev)
+            ops.warp_bwd_weights(acts_d, scratch_d, count, cap, wg)
+            torch.cuda.synchronize()
+            e = []
+            for l in (3, 2, 1):
+                got = wg[off[l]:off[l] + 128 * 128].view(128, 128).double().cpu()
+                e.append(float(((got - ref[l]) ** 2).mean().sqrt() / (ref[l] ** 2).mean().sqrt()))
+                gb = wg[off[l] + 128 * 128:off[l] + 128 * 128 + 128].double().cpu()
+                assert float((gb - refb[l]).abs().max()) <= 1e-5 * float(refb[l].abs().max()), f'bias gradient of layer {l}, mode {mode}'
+            err[mode & 16] = e
+    finally:
+        _lib.set_option('mlp_split', default)
+    for l, a, b in zip((3, 2, 1), err[0], err[16]):
+        assert b <= 1.25 * a + 1e-9 and b < 5e-6, f'W{l} gradient: fp32 chain {a:.3e}, split chain {b:.3e}'
