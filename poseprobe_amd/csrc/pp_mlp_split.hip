@@ -1520,8 +1520,8 @@ __device__ __forceinline__ void wgs_compute(const float* __restrict__ Ybuf, cons
 // leave the registers the conversion needs; the persistent work-groups of a layer walk its tiles from the end of the row range
 // (what the data-gradient kernel wrote last is what the Infinity Cache still holds).
 template <int KX, int CSTEP>
-__device__ __forceinline__ void wgs_layer(const WgradOperands& L, int R, int ntiles, float* __restrict__ Yb0, float* __restrict__ Xb0,
-                                          float* __restrict__ Yb1, float* __restrict__ Xb1) {
+__device__ __forceinline__ void wgs_layer(const WgradOperands& L, int R, int ntiles, int wg, int nwg, float* __restrict__ Yb0,
+                                          float* __restrict__ Xb0, float* __restrict__ Yb1, float* __restrict__ Xb1) {
   constexpr int NB = KX / 64;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, lh = lane >> 5;
@@ -1540,14 +1540,14 @@ __device__ __forceinline__ void wgs_layer(const WgradOperands& L, int R, int nti
       __syncthreads();
     }
   };
-  const int first = ntiles - 1 - (int)blockIdx.x;
+  const int first = ntiles - 1 - wg;
   wgs_issue<KX>(L, first * TILE_ROWS, R, Yb0, Xb0, wid, lane);
   // two tiles per iteration keep the buffer assignment static
 #ifdef MS_TIMERS
   unsigned long long tsum[16] = {0}, tprev = __builtin_readcyclecounter();
 #endif
-  for (int t0 = first; t0 >= 0; t0 -= 2 * (int)gridDim.x) {
-    const int t1 = t0 - (int)gridDim.x, t2 = t1 - (int)gridDim.x;
+  for (int t0 = first; t0 >= 0; t0 -= 2 * nwg) {
+    const int t1 = t0 - nwg, t2 = t1 - nwg;
     TICK(4);
     PP_WAIT_VMEM(); __syncthreads();
     TICK(0);
@@ -1597,18 +1597,22 @@ __device__ __forceinline__ void wgs_layer(const WgradOperands& L, int R, int nti
 
 template <int KXC, int CSTEP>
 __global__ __launch_bounds__(256) void k_wgrad_chain_s(WgradOperands LA, WgradOperands LB, WgradOperands LC,
-                                                       const int32_t* __restrict__ count, int rmul, int rcap) {
+                                                       const int32_t* __restrict__ count, int rmul, int rcap, int nwg_ab, int nwg_c) {
   __shared__ __attribute__((aligned(16))) float Yb0[TILE_ROWS * 128];
   __shared__ __attribute__((aligned(16))) float Xb0[TILE_ROWS * 128];
   __shared__ __attribute__((aligned(16))) float Yb1[TILE_ROWS * 128];
   __shared__ __attribute__((aligned(16))) float Xb1[TILE_ROWS * 128];
   const int R = min(count[0] * rmul, rcap);
   const int ntiles = (R + TILE_ROWS - 1) / TILE_ROWS;
-  if ((int)blockIdx.x >= ntiles) return;
+  // work-groups 0 .. nwg_ab - 1: layer A, the next nwg_ab: layer B, the last nwg_c: layer C (fewer when its operand is narrower)
+  const int bx = blockIdx.x;
+  const int layer = bx < nwg_ab ? 0 : (bx < 2 * nwg_ab ? 1 : 2);
+  const int wg = bx - layer * nwg_ab, nwg = layer < 2 ? nwg_ab : nwg_c;
+  if (wg >= ntiles) return;
   // one copy of the layer code per operand width (three calls would triple the instruction footprint)
-  const WgradOperands L = blockIdx.y == 0 ? LA : (blockIdx.y == 1 ? LB : LC);
-  if (KXC == 128 || blockIdx.y < 2) wgs_layer<128, CSTEP>(L, R, ntiles, Yb0, Xb0, Yb1, Xb1);
-  else wgs_layer<KXC, CSTEP>(L, R, ntiles, Yb0, Xb0, Yb1, Xb1);
+  const WgradOperands L = layer == 0 ? LA : (layer == 1 ? LB : LC);
+  if (KXC == 128 || layer < 2) wgs_layer<128, CSTEP>(L, R, ntiles, wg, nwg, Yb0, Xb0, Yb1, Xb1);
+  else wgs_layer<KXC, CSTEP>(L, R, ntiles, wg, nwg, Yb0, Xb0, Yb1, Xb1);
 }
 
 int pp_launch_wgrad_chain_s(const float* YA, const float* XA, float* WA, const float* YB, const float* XB, float* WB,
@@ -1616,11 +1620,16 @@ int pp_launch_wgrad_chain_s(const float* YA, const float* XA, float* WA, const f
                             hipStream_t st, float* bA, float* bB, float* bC) {
   WgradOperands LA{YA, XA, WA, bA}, LB{YB, XB, WB, bB}, LC{YC, XC, WC, bC};
   const int ntiles = pp_div_up(rcap, TILE_ROWS);
-  const int per_layer = PP_FUSED_WGS / 3;                           // persistent work-groups per layer: at most one per CU over the three layers
-  const int gx = ntiles < per_layer ? ntiles : per_layer;
+  // persistent work-groups, at most one per CU over the three layers, shared out in proportion to the layers' work
+  const int wgs = PP_FUSED_WGS;
+  // (a 64-wide layer costs 3/4 of a 128-wide one: three instead of four operand fragments to convert per 16-row group - the
+  // conversion, not the MFMA count, is what the time follows)
+  int nab = kxc == 128 ? wgs / 3 : (wgs * 4) / 11, nc = kxc == 128 ? wgs / 3 : wgs - 2 * ((wgs * 4) / 11);
+  if (nab > ntiles) nab = ntiles;
+  if (nc > ntiles) nc = ntiles;
   if (kxc == 128)
-    hipLaunchKernelGGL((k_wgrad_chain_s<128, 4>), dim3(gx, 3), dim3(256), 0, st, LA, LB, LC, count, rmul, rcap);
+    hipLaunchKernelGGL((k_wgrad_chain_s<128, 4>), dim3(2 * nab + nc), dim3(256), 0, st, LA, LB, LC, count, rmul, rcap, nab, nc);
   else
-    hipLaunchKernelGGL((k_wgrad_chain_s<64, 1>), dim3(gx, 3), dim3(256), 0, st, LA, LB, LC, count, rmul, rcap);
+    hipLaunchKernelGGL((k_wgrad_chain_s<64, 1>), dim3(2 * nab + nc), dim3(256), 0, st, LA, LB, LC, count, rmul, rcap, nab, nc);
   return 0;
 }
