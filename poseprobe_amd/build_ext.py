@@ -17,9 +17,12 @@ OBJ = os.path.join(CSRC, '_obj')
 OUT = os.path.join(HERE, 'libposeprobe_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-Wno-pass-failed', '-Wno-unused-result',
          '-Wno-unused-value']
-# per-source flags.  pp_mlp_split.hip: the SLP vectoriser turns the epilogue arithmetic into v_pk_*_f32, which on gfx950 does not
-# overlap with MFMAs (tools/mfma_valu_probe.hip: two v_pk_fma_f32 between MFMAs double the loop time, four plain VALU are free)
-SOURCE_FLAGS = {'pp_mlp_split.hip': ['-fno-slp-vectorize']}
+# per-source flags.  The files with split-precision MFMA kernels: the SLP vectoriser turns adjacent scalar fp32 arithmetic (epilogues, operand
+# conversion) into v_pk_*_f32, which on gfx950 does not overlap with MFMAs (tools/mfma_valu_probe.hip: two v_pk_fma_f32 between
+# MFMAs double the loop time, four plain VALU are free; MI355X_MICROARCH.md lists the same).  Measured: k_gemm_tn_split 123 -> 110 us, scene step 3.22 -> 3.10 ms.  NOT for
+# pp_mlp_fused.hip: its fp32-instruction kernels are matrix-pipe bound and their serial epilogues are shorter packed
+# (k_warp_fused_bwd 256 -> 282 us without SLP)
+SOURCE_FLAGS = {f: ['-fno-slp-vectorize'] for f in ('pp_mlp_split.hip', 'pp_nerf.hip')}
 
 
 def sources():
