@@ -27,14 +27,39 @@ __device__ __forceinline__ float pp_split_scale(float mx) {
   return ldexpf(1.f, 15 - e);
 }
 
+// four values -> scaled hi | lo halves (see pp_split8 below for the instruction choice)
 __device__ __forceinline__ void pp_split4(float4 x, float s, pp_half4& hi, pp_half4& lo) {
-  const float v[4] = {x.x * s, x.y * s, x.z * s, x.w * s};
+  const float x0 = x.x * s, x1 = x.y * s, x2 = x.z * s, x3 = x.w * s;
+  unsigned h01, h23, l01, l23;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h01) : "v"(x0), "v"(x1));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h23) : "v"(x2), "v"(x3));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h01), "v"(x0));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(x1));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(x2));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(x3));
+  typedef unsigned pp_u2 __attribute__((ext_vector_type(2)));
+  const pp_u2 hv = {h01, h23}, lv = {l01, l23};
+  hi = __builtin_bit_cast(pp_half4, hv);
+  lo = __builtin_bit_cast(pp_half4, lv);
+}
+
+// eight values -> scaled hi | lo halves, three instructions per PAIR after the scaling: hi pair by v_cvt_pk_f16_f32, lo = x - hi by
+// v_fma_mixlo / mixhi_f16 (fp32 fma on the f16 hi half, rounded once into the packed result).  Inline assembly: the compiler
+// expands the same arithmetic into five instructions per element (and, with the SLP vectoriser on, into v_pk_*_f32, which cost 16
+// cycles each beside MFMAs).
+__device__ __forceinline__ void pp_split8(const float (&v)[8], float s, pp_half8& h, pp_half8& l) {
+  unsigned hh[4], ll[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const _Float16 h = (_Float16)v[i];
-    hi[i] = h;
-    lo[i] = (_Float16)(v[i] - (float)h);
+  for (int k = 0; k < 4; ++k) {
+    const float x0 = v[2 * k] * s, x1 = v[2 * k + 1] * s;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hh[k]) : "v"(x0), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ll[k]) : "v"(hh[k]), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(ll[k]) : "v"(hh[k]), "v"(x1));
   }
+  typedef unsigned pp_u4 __attribute__((ext_vector_type(4)));
+  const pp_u4 hv = {hh[0], hh[1], hh[2], hh[3]}, lv = {ll[0], ll[1], ll[2], ll[3]};
+  h = __builtin_bit_cast(pp_half8, hv);
+  l = __builtin_bit_cast(pp_half8, lv);
 }
 
 __device__ __forceinline__ void pp_record_max(float* slot, float v) {      // v >= 0 ; one atomic per wavefront
@@ -232,13 +257,10 @@ static __global__ __launch_bounds__(256) void k_gemm_tn_split(const float* __res
   };
   auto store_col = [&](const float4 (&r)[8], int j, float s, _Float16* Th, _Float16* Tl) {
     pp_half8 h, l;
+    float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float x = (j == 0 ? r[i].x : j == 1 ? r[i].y : j == 2 ? r[i].z : r[i].w) * s;
-      const _Float16 hh = (_Float16)x;
-      h[i] = hh;
-      l[i] = (_Float16)(x - (float)hh);
-    }
+    for (int i = 0; i < 8; ++i) v[i] = j == 0 ? r[i].x : j == 1 ? r[i].y : j == 2 ? r[i].z : r[i].w;
+    pp_split8(v, s, h, l);
     const int o = (c4 * 4 + j) * LDC + ((rblk ^ (c4 & 7)) * 8);
     *reinterpret_cast<pp_half8*>(Th + o) = h;
     *reinterpret_cast<pp_half8*>(Tl + o) = l;

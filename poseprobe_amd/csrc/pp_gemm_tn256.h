@@ -18,21 +18,6 @@
 #define PP_TN_GLOBAL(p) ((const __attribute__((address_space(1))) void*)(p))
 #define PP_TN_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
-__device__ __forceinline__ void tn256_split(const float (&v)[8], float s, pp_half8& h, pp_half8& l) {
-  unsigned hh[4], ll[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float x0 = v[2 * k] * s, x1 = v[2 * k + 1] * s;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hh[k]) : "v"(x0), "v"(x1));
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ll[k]) : "v"(hh[k]), "v"(x0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(ll[k]) : "v"(hh[k]), "v"(x1));
-  }
-  typedef unsigned u4 __attribute__((ext_vector_type(4)));
-  const u4 hv = {hh[0], hh[1], hh[2], hh[3]}, lv = {ll[0], ll[1], ll[2], ll[3]};
-  h = __builtin_bit_cast(pp_half8, hv);
-  l = __builtin_bit_cast(pp_half8, lv);
-}
-
 // grid = persistent work-groups (one per CU: 128 KB of LDS) of 512 threads; Y [R][ldy] (256 columns used), X [R][ldx] (256
 // columns used), Wbar [256][ldw]
 static __global__ __launch_bounds__(512, 1) void k_gemm_tn256(const float* __restrict__ Y, int ldy, const float* __restrict__ X, int ldx,
@@ -95,14 +80,14 @@ static __global__ __launch_bounds__(512, 1) void k_gemm_tn256(const float* __res
 #pragma unroll
           for (int j = 0; j < 8; ++j) bsum[t] += v[j];
         }
-        tn256_split(v, sY, ah[t], al[t]);
+        pp_split8(v, sY, ah[t], al[t]);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = xp[(16 * ks + j) * 256 + 32 * u];
-        tn256_split(v, sX, bh[u], bl[u]);
+        pp_split8(v, sX, bh[u], bl[u]);
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t)
