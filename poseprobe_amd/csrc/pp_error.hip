@@ -21,7 +21,7 @@ struct PPOptionDef { const char* name; int dflt, lo, hi; };
 static const PPOptionDef g_opt_def[PP_OPT_COUNT] = {
     {"mlp_fused", 1, 0, 1},        {"wgrad_split", 0, 0, 1},         {"grid_chunks", 0, 0, 4096},
     {"nerf_split", 1, 0, 1},       {"nerf_split_tn", 1, 0, 1},       {"nerf_bitmask", 1, 0, 1},
-    {"nerf_gemm_wgs", 256, 1, 4096}, {"nerf_tn_ch", 64, 32, 64},     {"nerf_tn_split_wgs", 64, 1, 4096},
+    {"nerf_gemm_wgs", 256, 1, 4096}, {"nerf_tn_ch", 64, 32, 64},     {"nerf_tn_split_wgs", 128, 1, 4096},
     {"nerf_tn_wgs", 128, 1, 4096}, {"nerf_bn", 128, 128, 256},       {"nerf_planes", 1, 0, 1},
     {"sdf_index_exact", 0, 0, 1},   {"mlp_split", 31, 0, 31},
     {"nerf_tn256", 0, 0, 1},

@@ -617,7 +617,9 @@ static void nerf_gemm_tn(hipStream_t st, const float* Y, int ldy, int N, const f
   }
   const int blocks = (N / 128) * pp_div_up(Kx, 128);
   dim3 b(256);
-  if (NERF_SPLIT && NERF_SPLIT_TN && y_max && x_max) {     // one work-group per CU measured best (3.69 vs 3.85 ms at two)
+  if (NERF_SPLIT && NERF_SPLIT_TN && y_max && x_max) {     // two work-groups per CU (option nerf_tn_split_wgs = 128) since the operand conversion
+                                                           // is three instructions per pair: 2.90 vs 2.99 ms per scene step (round 1, with the
+                                                           // compiler's conversion: one per CU was best, 3.69 vs 3.85 ms)
     dim3 gs(NERF_TN_SPLIT_WGS * 4 / blocks, blocks);
     hipLaunchKernelGGL(k_gemm_tn_split, gs, b, 0, st, Y, ldy, X, ldx, Kx, Wbar, ldx, bbar, count, rows, y_max, x_max);
     return;
