@@ -28,6 +28,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TILE_ROWS 64
 
 int pp_fused_wgs() {
+  const int opt = pp_opt(PP_OPT_MLP_WGS);
+  if (opt > 0) return opt;
   static int n = 0;
   if (n == 0) {
     int dev = 0, cus = 0;
