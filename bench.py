@@ -53,7 +53,7 @@ def launch_ranks(n_gpus, argv, device_count=None, launcher=None, out=None):
         import torch
         device_count = torch.cuda.device_count
     have = int(device_count())
-    if have < n_gpus:
+    if have < n_gpus and os.environ.get('PP_BENCH_SHARED_GPU') != '1':
         sys.stderr.write(f'bench.py: --gpus {n_gpus} requested but only {have} GPU(s) are visible on this node\n')
         return 3
     s = socket.socket()
@@ -450,6 +450,11 @@ def main():
         sys.stderr.write(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run '
                          f'--nproc-per-node {args.gpus}, or without RANK in the environment to let bench.py start the ranks)\n')
         sys.exit(2)
+    # PP_BENCH_SHARED_GPU=1: REHEARSAL of the N > 1 code path on a box with fewer GPUs - the ranks share the visible cards and the
+    # collectives travel over gloo (RCCL refuses two ranks on one device); the record says so and is not a measurement
+    rehearsal = os.environ.get('PP_BENCH_SHARED_GPU') == '1'
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dctx = None
@@ -458,7 +463,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         from poseprobe_amd.dist import DistContext
         dctx = DistContext()
 
@@ -591,13 +599,23 @@ def main():
     split_of = {'k_warp_fused_fwd': split_bits & 1, 'k_warp_fused_bwd': split_bits & 2, 'k_rgb_fused_fwd': split_bits & 4,
                 'k_rgb_fused_bwd': split_bits & 8, 'k_wgrad_chain<128> (warp)': split_bits & 16, 'k_wgrad_chain<64> (rgbnet)': split_bits & 16}
 
+    # compulsory HBM bytes per sample of the same kernels (fp32 activations between the kernels of a chain: every stored layer is 4 rows x
+    # 128 x 4 B per sample in the warp net, 128 x 4 B in rgbnet): fwd = inputs + stored activations + outputs; bwd = the activation
+    # rows it gates by (warp: all of X3 for the output layer's weight gradient, the primal row of X0..X2) + upstream gradients + the
+    # three Ybar it writes; weight gradients = Ybar + X of three layers.  The warp kernels move 3-4 TB/s: they sit beside the HBM roof too.
+    hbm_bytes = {'k_warp_fused_fwd': 12 + 4 * 2048 + 64, 'k_warp_fused_bwd': 2048 + 3 * 512 + 64 + 12 + 3 * 2048 + 12,
+                 'k_wgrad_chain<128> (warp)': 3 * (2048 + 2048), 'k_rgb_fused_fwd': 256 + 3 * 512 + 12,
+                 'k_rgb_fused_bwd': 3 * 512 + 12 + 12 + 3 * 512 + 256, 'k_wgrad_chain<64> (rgbnet)': (256 + 512) + 2 * (512 + 512)}
+
     def price(name, fl, ms, samples):
         tf = fl * samples / (ms * 1e-3) / 1e12
+        gbs = hbm_bytes[name] * samples / (ms * 1e-3) / 1e9
+        hbm = {'hbm_bytes_per_sample': hbm_bytes[name], 'hbm_gbs': gbs, 'hbm_frac': gbs / HBM_PEAK_GBS}
         if split_of.get(name):
             return {'ms': ms, 'algorithmic_tflops': tf, 'pipe': 'fp16 MFMA 32x32x16, 3 products per fp32 product', 'issued_tflops': 3 * tf,
-                    'peak': FP16_MFMA_PEAK_TF, 'frac': 3 * tf / FP16_MFMA_PEAK_TF}
+                    'peak': FP16_MFMA_PEAK_TF, 'frac': 3 * tf / FP16_MFMA_PEAK_TF, **hbm}
         return {'ms': ms, 'algorithmic_tflops': tf, 'pipe': 'fp32 MFMA 32x32x2', 'issued_tflops': tf, 'peak': FP32_MFMA_PEAK_TF,
-                'frac': tf / FP32_MFMA_PEAK_TF}
+                'frac': tf / FP32_MFMA_PEAK_TF, **hbm}
 
     kernels = {name: price(name, fl, mean_ms(name), Mx) for name, fl in flops.items()}
     mlp_ms = float(np.sum([k['ms'] for k in kernels.values()]))
@@ -616,14 +634,15 @@ def main():
     grid_gbs = grid_bytes / (grid_ms * 1e-3) / 1e9
     roofline_grid = {'bound': 'hbm', 'kernel': 'k_grid_tv_adam (fused TV-grad + Adam + zero-grad over k0, gradient touched only where the scatter marked)',
                      'achieved': grid_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': grid_gbs / HBM_PEAK_GBS,
-                     'traffic': pmc_traffic(G, (xe - xb) * Y * Z, marked < 1.0), 'traffic_source': 'committed rocprofv3 PMC pass (profiles/), not this run',
+                     'traffic': pmc_traffic(G, (xe - xb) * Y * Z, marked < 1.0) if world == 1 else None,
+                     'traffic_source': 'committed rocprofv3 PMC pass of the single-GPU run (profiles/), not this run',
                      'ms_per_launch': grid_ms, 'algorithmic_bytes_per_launch': grid_bytes, 'grad_voxels_marked': marked}
     def mfma_roofline(name, what, ms):
         pr = price(name, flops[name], ms, M)
         return {'bound': 'mfma', 'kernel': f'{name} ({what}; {pr["pipe"]})', 'achieved': pr['issued_tflops'], 'peak': pr['peak'],
                 'unit': 'TFLOP/s', 'frac': pr['frac'], 'traffic': None, 'ms_per_launch': ms,
                 'algorithmic_flops_per_launch': flops[name] * M, 'flop_per_sample': flops[name], 'samples': M,
-                'algorithmic_tflops': pr['algorithmic_tflops']}
+                'algorithmic_tflops': pr['algorithmic_tflops'], 'hbm_gbs': pr['hbm_gbs'], 'hbm_frac': pr['hbm_frac']}
 
     # the longest kernel of the timed step among the three live-timed candidates
     candidates = [(grid_ms, roofline_grid),
@@ -666,6 +685,8 @@ def main():
                              'traffic': None, 'ms_per_step': mlp_ms, 'flop_per_sample': flop_per_sample, 'kernels': kernels,
                              'measured': f'untimed post-pass of {extra} steps, one HIP event pair per kernel'},
         }
+        if rehearsal:
+            out['rehearsal'] = f'{world} ranks sharing {torch.cuda.device_count()} GPU(s), gloo transport: code-path check, NOT a measurement'
         out['dual_branch'] = dual
         if dual is not None:
             out['dual_branch_rays_per_s'] = dual['coarse_phase']['rays_per_s']

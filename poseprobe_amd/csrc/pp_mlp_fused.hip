@@ -29,7 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int pp_fused_wgs() {
   const int opt = pp_opt(PP_OPT_MLP_WGS);
-  if (opt > 0) return opt;
+  if (opt > 0) return opt < 16 ? 16 : opt;     // the weight-gradient chains share the work-groups out over three layers
   static int n = 0;
   if (n == 0) {
     int dev = 0, cus = 0;
