@@ -402,9 +402,9 @@ int pp_march_dvgo_fwd(const float* alpha, const float* rgb, const float* step_w,
  * Rays: center[R,3], ray[R,3] (un-normalised), depth[R,S]; sample m = r * S + s.  bands[14] (device) = BARF's coarse-to-fine
  * weights of the 10 point bands then the 4 view bands (ones without a schedule).  count: device int32 holding R * S.
  * Workspaces in floats from pp_nerf_workspace(R * S, R, &acts, &scratch).
- * Arithmetic: fp32 operands and accumulation; the forward / data-gradient matrix products are evaluated as three fp16
- * products per fp32 product (error against fp64 equal to the fp32 matrix instructions'), the weight-gradient
- * products on the fp32 matrix instructions; environment PP_NERF_SPLIT=0 (read at load time) selects the latter for all. */
+ * Arithmetic: fp32 operands and accumulation; the forward / data-gradient / weight-gradient matrix products are evaluated as
+ * three fp16 products per fp32 product (error against fp64 equal to the fp32 matrix instructions'); options
+ * nerf_split = 0 / nerf_split_tn = 0 (pp_set_option) select the fp32 matrix instructions instead. */
 int pp_nerf_layout(int64_t* offsets);
 int pp_nerf_workspace(int64_t n_samples, int64_t n_rays, int64_t* acts_floats, int64_t* scratch_floats);
 int pp_nerf_fwd(const float* params, const float* center, const float* ray, const float* depth, const float* bands,

@@ -87,8 +87,9 @@ static int64_t nerf_acts_floats(int64_t M) {
 static const int64_t NERF_WT_FLOATS = 5 * 65536 + 320 * 256 + 256 * 288 + 64 * 256 + 288 * 128;
 // images of the transposed weights for the data-gradient GEMMs: R0^T (K = 128), W7^T (K = 288), W1^T .. W6^T (K = 256)
 static const int64_t NERF_WTIMG_FLOATS = 256 * (128 + 288 + 6 * 256);
+static const int64_t NERF_PART_FLOATS = 512 * 392;       // NERF_PART_WGS x NERF_PART_LD: partial rows of the thin heads' backward kernels
 static int64_t nerf_scratch_floats(int64_t M, int64_t R) {
-  return M * (320 * 2 + 64 * 2) + R * (128 + 32) + NERF_WT_FLOATS + NERF_WTIMG_FLOATS;
+  return M * (320 * 2 + 64 * 2) + R * (128 + 32) + NERF_WT_FLOATS + NERF_WTIMG_FLOATS + NERF_PART_FLOATS;
 }
 
 extern "C" int pp_nerf_workspace(int64_t n_samples, int64_t n_rays, int64_t* acts_floats, int64_t* scratch_floats) {
@@ -114,22 +115,35 @@ __device__ __forceinline__ float nerf_enc_elem(int j, int L, const float* __rest
 __global__ __launch_bounds__(256) void k_nerf_encode(const float* __restrict__ center, const float* __restrict__ ray,
                                                      const float* __restrict__ depth, const float* __restrict__ bands, int M, int S,
                                                      float* __restrict__ enc, float* __restrict__ a3, float* __restrict__ a7) {
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // a wavefront takes four consecutive samples: the view encoding (sines / cosines of the ray's unit direction) is evaluated once
+  // per ray it meets, not once per sample
+  const int mw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
   const int j = threadIdx.x & 63;
-  if (m >= M) return;
-  const int r = m / S;
-  const float t = depth[m];
-  const float d[3] = {ray[r * 3], ray[r * 3 + 1], ray[r * 3 + 2]};
-  float x[3];
+  int rprev = -1;
+  float d[3] = {0.f, 0.f, 0.f}, o[3] = {0.f, 0.f, 0.f}, ve = 0.f;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) x[c] = center[r * 3 + c] + d[c] * t;
-  const float e = nerf_enc_elem(j, NERF_L3D, x, bands);
-  enc[(size_t)m * 64 + j] = e;
-  a3[(size_t)m * 320 + 256 + j] = e;
-  if (j < 32) {
-    const float n = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
-    const float u[3] = {d[0] / n, d[1] / n, d[2] / n};
-    a7[(size_t)m * 288 + 256 + j] = nerf_enc_elem(j, NERF_LV, u, bands + NERF_L3D);
+  for (int i = 0; i < 4; ++i) {
+    const int m = mw + i;
+    if (m >= M) return;
+    const int r = m / S;
+    if (r != rprev) {
+      rprev = r;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { d[c] = ray[r * 3 + c]; o[c] = center[r * 3 + c]; }
+      if (j < 32) {
+        const float n = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+        const float u[3] = {d[0] / n, d[1] / n, d[2] / n};
+        ve = nerf_enc_elem(j, NERF_LV, u, bands + NERF_L3D);
+      }
+    }
+    const float t = depth[m];
+    float x[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) x[c] = o[c] + d[c] * t;
+    const float e = nerf_enc_elem(j, NERF_L3D, x, bands);
+    enc[(size_t)m * 64 + j] = e;
+    a3[(size_t)m * 320 + 256 + j] = e;
+    if (j < 32) a7[(size_t)m * 288 + 256 + j] = ve;
   }
 }
 
@@ -137,9 +151,12 @@ __global__ __launch_bounds__(256) void k_nerf_encode(const float* __restrict__ c
 // (the sines / cosines and the view encoding are bounded by 1) -> operand-maximum slots of the three consumers
 __global__ __launch_bounds__(256) void k_nerf_enc_bound(const float* __restrict__ center, const float* __restrict__ ray,
                                                         const float* __restrict__ depth, int R, int S, float* __restrict__ mx) {
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // one wavefront per ray
+  // one wavefront per ray, a few rays per wavefront (<= 64 work-groups): the three slots see one atomic per WORK-GROUP - with a
+  // wavefront per ray the 3 R same-address atomics were the whole run time (37 us at 1023 rays)
+  __shared__ float red[4];
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float v = 1.f;
-  if (r < R) {
+  for (int r = blockIdx.x * 4 + wid; r < R; r += gridDim.x * 4) {
     float t0 = 3.0e38f, t1 = -3.0e38f;            // smallest / largest depth of the ray, whatever the sample order
     for (int i = lane; i < S; i += 64) { const float t = depth[(size_t)r * S + i]; t0 = fminf(t0, t); t1 = fmaxf(t1, t); }
 #pragma unroll
@@ -150,9 +167,14 @@ __global__ __launch_bounds__(256) void k_nerf_enc_bound(const float* __restrict_
       v = fmaxf(v, fmaxf(fabsf(o + d * t0), fabsf(o + d * t1)));
     }
   }
-  pp_record_max(mx + MX_ENC, v);
-  pp_record_max(mx + MX_A0 + 3, v);
-  pp_record_max(mx + MX_A0 + 7, 1.f);
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    atomicMax(reinterpret_cast<unsigned int*>(mx + MX_ENC), __float_as_uint(v));
+    atomicMax(reinterpret_cast<unsigned int*>(mx + MX_A0 + 3), __float_as_uint(v));
+    atomicMax(reinterpret_cast<unsigned int*>(mx + MX_A0 + 7), __float_as_uint(1.f));
+  }
 }
 
 // largest |w| of the nine GEMM weight matrices (blockIdx.x selects; the last feature layer includes its density row)
@@ -203,83 +225,156 @@ __global__ __launch_bounds__(256) void k_nerf_rgb_fwd(const float* __restrict__ 
   }
 }
 
-// colour head backward: dH[m][j] = [h > 0] * sum_o gl_o R1[o][j], R1bar, br1bar ; 64 samples per work-group
+// The two thin heads' backward kernels leave their parameter-gradient sums and operand maxima as per-work-group PARTIAL rows
+// (part[blockIdx.x][NERF_PART_LD], no atomics), k_nerf_part_finish adds the rows up in a fixed order: deterministic, and the
+// kernels can run with as many work-groups as the streaming needs (round 1: 257 / 387 same-address atomics per work-group
+// forced 1024-row strips on 128 of the 256 CUs: 77 us for a 134 MB read).
+#define NERF_PART_WGS 512
+#define NERF_PART_LD 392          // rgb head: 3 x 128 weight sums, 3 bias sums, max | density head: 256 weight sums, bias sum, max
+
+// colour head backward: dH[m][j] = [h > 0] * sum_o gl_o R1[o][j], R1bar, br1bar ; 256-row strips, thread = (row phase of 4, feature),
+// eight rows in flight per thread
 #define NERF_STRIP 256
-__global__ __launch_bounds__(256) void k_nerf_rgb_bwd(const float* __restrict__ R1, const float* __restrict__ h,
+__global__ __launch_bounds__(512) void k_nerf_rgb_bwd(const float* __restrict__ R1, const float* __restrict__ h,
                                                       const float* __restrict__ rgb, const float* __restrict__ g_rgb, int M,
-                                                      float* __restrict__ dH, float* __restrict__ R1bar,
-                                                      float* __restrict__ br1bar, float* __restrict__ mx_dh) {
-  __shared__ float red[3 * 128 + 4];
-  const int m0 = blockIdx.x * NERF_STRIP;
-  if (m0 >= M) return;
-  const int half = threadIdx.x >> 7, j = threadIdx.x & 127;
+                                                      float* __restrict__ dH, float* __restrict__ part) {
+  __shared__ float red[3][3 * 128 + 4];
+  __shared__ float redm[8];
+  const int ph = threadIdx.x >> 7, j = threadIdx.x & 127;
   const float w[3] = {R1[j], R1[128 + j], R1[256 + j]};
   float wacc[3] = {0, 0, 0}, bacc = 0.f, hmax = 0.f;
-  const int mend = min(m0 + NERF_STRIP, M);
-  for (int m = m0 + half; m < mend; m += 2) {
-    float gl[3];
+  for (int m0 = blockIdx.x * NERF_STRIP; m0 < M; m0 += gridDim.x * NERF_STRIP) {
+    const int mend = min(m0 + NERF_STRIP, M);
+    for (int mb = m0 + ph; mb < mend; mb += 32) {
+      float x[8], g0[8], g1[8], g2[8];
 #pragma unroll
-    for (int o = 0; o < 3; ++o) { const float r = rgb[(size_t)m * 3 + o]; gl[o] = g_rgb[(size_t)m * 3 + o] * r * (1.f - r); }
-    const float x = h[(size_t)m * 128 + j];
-    wacc[0] += gl[0] * x; wacc[1] += gl[1] * x; wacc[2] += gl[2] * x;
-    const float hb = gl[0] * w[0] + gl[1] * w[1] + gl[2] * w[2];
-    dH[(size_t)m * 128 + j] = (x > 0.f) ? hb : 0.f;
-    hmax = fmaxf(hmax, fabsf(hb));
-    if (j < 3) bacc += gl[j];
+      for (int u = 0; u < 8; ++u) {
+        const int m = mb + 4 * u;
+        const bool ok = m < mend;
+        const int mm = ok ? m : m0;
+        x[u] = h[(size_t)mm * 128 + j];
+        const float r0 = rgb[(size_t)mm * 3], r1 = rgb[(size_t)mm * 3 + 1], r2 = rgb[(size_t)mm * 3 + 2];
+        g0[u] = ok ? g_rgb[(size_t)mm * 3] * r0 * (1.f - r0) : 0.f;
+        g1[u] = ok ? g_rgb[(size_t)mm * 3 + 1] * r1 * (1.f - r1) : 0.f;
+        g2[u] = ok ? g_rgb[(size_t)mm * 3 + 2] * r2 * (1.f - r2) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = mb + 4 * u;
+        wacc[0] += g0[u] * x[u]; wacc[1] += g1[u] * x[u]; wacc[2] += g2[u] * x[u];
+        const float hb = g0[u] * w[0] + g1[u] * w[1] + g2[u] * w[2];
+        if (m < mend) dH[(size_t)m * 128 + j] = (x[u] > 0.f) ? hb : 0.f;
+        hmax = fmaxf(hmax, fabsf(hb));
+        bacc += (j == 0) ? g0[u] : (j == 1) ? g1[u] : g2[u];          // used by j < 3 only
+      }
+    }
   }
-  if (mx_dh) pp_record_max(mx_dh, hmax);
-  if (half == 1) { for (int o = 0; o < 3; ++o) red[o * 128 + j] = wacc[o]; }
-  if (half == 1 && j < 3) red[384 + j] = bacc;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) hmax = fmaxf(hmax, __shfl_xor(hmax, o, 64));
+  if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = hmax;
+  if (ph > 0) {
+    for (int o = 0; o < 3; ++o) red[ph - 1][o * 128 + j] = wacc[o];
+    if (j < 3) red[ph - 1][384 + j] = bacc;
+  }
   __syncthreads();
-  if (half == 0) { for (int o = 0; o < 3; ++o) atomicAdd(&R1bar[o * 128 + j], wacc[o] + red[o * 128 + j]); }
-  if (half == 0 && j < 3) atomicAdd(&br1bar[j], bacc + red[384 + j]);
+  float* __restrict__ row = part + (size_t)blockIdx.x * NERF_PART_LD;
+  if (ph == 0) {
+    for (int o = 0; o < 3; ++o) row[o * 128 + j] = (wacc[o] + red[0][o * 128 + j]) + (red[1][o * 128 + j] + red[2][o * 128 + j]);
+    if (j < 3) row[384 + j] = (bacc + red[0][384 + j]) + (red[1][384 + j] + red[2][384 + j]);
+  }
+  if (threadIdx.x == 0) {
+    float v = redm[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) v = fmaxf(v, redm[i]);
+    row[387] = v;
+  }
 }
 
 // density head backward: column 256 of the last feature layer's output gradient carries d raw; wd / bd gradients.
-// Work-group = 16 wavefronts x 64 lanes over a strip of 1024 rows; a lane owns 4 consecutive columns (float4 loads), a
-// wavefront every 16th row, so 16 rows are in flight per work-group while only ONE set of 257 atomics per 1024 rows reaches
-// the (shared, hence serialised) gradient addresses - smaller strips are slower: 64 rows per work-group take 223 us, 512 with
-// four wavefronts 106 us at 131 k samples.
-#define NERF_DSTRIP 1024
-__global__ __launch_bounds__(1024) void k_nerf_density_bwd(const float* __restrict__ a6, const float* __restrict__ raw,
-                                                           const float* __restrict__ g_density, int M,
-                                                           float* __restrict__ dY7, float* __restrict__ wdbar,
-                                                           float* __restrict__ bdbar, float* __restrict__ mx_p) {
-  __shared__ float4 red[16][64];
-  __shared__ float redb[16];
-  const int m0 = blockIdx.x * NERF_DSTRIP;
-  if (m0 >= M) return;
+// 256-row strips on eight wavefronts; a lane owns 4 consecutive columns (float4 loads), a wavefront every 8th row, eight rows in
+// flight per lane.
+#define NERF_DSTRIP 256
+__global__ __launch_bounds__(512) void k_nerf_density_bwd(const float* __restrict__ a6, const float* __restrict__ raw,
+                                                          const float* __restrict__ g_density, int M,
+                                                          float* __restrict__ dY7, float* __restrict__ part) {
+  __shared__ float4 red[8][64];
+  __shared__ float redb[8], redm[8];
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float bacc = 0.f, gmax = 0.f;
-  const int mend = min(m0 + NERF_DSTRIP, M);
-#pragma unroll 4
-  for (int m = m0 + wid; m < mend; m += 16) {
-    const float g = g_density[m] * nerf_dsoftplus(raw[m]);
-    const float4 x = *reinterpret_cast<const float4*>(a6 + (size_t)m * 256 + lane * 4);
-    acc.x += g * x.x; acc.y += g * x.y; acc.z += g * x.z; acc.w += g * x.w;
-    if (lane < 32) dY7[(size_t)m * 288 + 256 + lane] = (lane == 0) ? g : 0.f;
-    bacc += g;
-    gmax = fmaxf(gmax, fabsf(g));
+  for (int m0 = blockIdx.x * NERF_DSTRIP; m0 < M; m0 += gridDim.x * NERF_DSTRIP) {
+    const int mend = min(m0 + NERF_DSTRIP, M);
+    for (int mb = m0 + wid; mb < mend; mb += 64) {
+      float4 x[8];
+      float g[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = mb + 8 * u;
+        const bool ok = m < mend;
+        const int mm = ok ? m : m0;
+        x[u] = *reinterpret_cast<const float4*>(a6 + (size_t)mm * 256 + lane * 4);
+        g[u] = ok ? g_density[mm] * nerf_dsoftplus(raw[mm]) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = mb + 8 * u;
+        acc.x += g[u] * x[u].x; acc.y += g[u] * x[u].y; acc.z += g[u] * x[u].z; acc.w += g[u] * x[u].w;
+        if (m < mend && lane < 32) dY7[(size_t)m * 288 + 256 + lane] = (lane == 0) ? g[u] : 0.f;
+        bacc += g[u];
+        gmax = fmaxf(gmax, fabsf(g[u]));
+      }
+    }
   }
-  if (mx_p) pp_record_max(mx_p, gmax);
   red[wid][lane] = acc;
-  if (lane == 0) redb[wid] = bacc;
+  if (lane == 0) { redb[wid] = bacc; redm[wid] = gmax; }        // g is uniform over the wavefront
   __syncthreads();
+  float* __restrict__ row = part + (size_t)blockIdx.x * NERF_PART_LD;
   if (wid == 0) {
     float4 s = red[0][lane];
-    float sb = redb[0];
 #pragma unroll
-    for (int w = 1; w < 16; ++w) {
+    for (int w = 1; w < 8; ++w) {
       const float4 t = red[w][lane];
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-      sb += redb[w];
     }
-    atomicAdd(&wdbar[lane * 4 + 0], s.x);
-    atomicAdd(&wdbar[lane * 4 + 1], s.y);
-    atomicAdd(&wdbar[lane * 4 + 2], s.z);
-    atomicAdd(&wdbar[lane * 4 + 3], s.w);
-    if (lane == 0) atomicAdd(&bdbar[0], sb);
+    *reinterpret_cast<float4*>(row + lane * 4) = s;
+    if (lane == 0) {
+      float sb = redb[0], sm = redm[0];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) { sb += redb[w]; sm = fmaxf(sm, redm[w]); }
+      row[256] = sb;
+      row[257] = sm;
+    }
+  }
+}
+
+// dst0[c] += sum_rows part[row][c] (c < n0), dst1[c - n0] += ... (n0 <= c < n0 + n1), slot = max(slot, max_rows part[row][n0 + n1]);
+// rows are added in a fixed order (sixteen interleaved runs, then the run sums in order)
+__global__ __launch_bounds__(1024) void k_nerf_part_finish(const float* __restrict__ part, int rows, float* __restrict__ dst0, int n0,
+                                                           float* __restrict__ dst1, int n1, float* __restrict__ mx_slot) {
+  __shared__ float red[16][64];
+  const int l = threadIdx.x & 63, c = blockIdx.x * 64 + l, q = threadIdx.x >> 6;
+  const int ncols = n0 + n1 + 1;
+  const bool is_max = c == n0 + n1;
+  float acc = 0.f;
+  if (c < ncols) {
+#pragma unroll 8
+    for (int r = q; r < rows; r += 16) {
+      const float v = part[(size_t)r * NERF_PART_LD + c];
+      acc = is_max ? fmaxf(acc, v) : acc + v;
+    }
+  }
+  red[q][l] = acc;
+  __syncthreads();
+  if (q != 0 || c >= ncols) return;
+  float v = red[0][l];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) v = is_max ? fmaxf(v, red[i][l]) : v + red[i][l];
+  if (is_max) {
+    if (mx_slot) atomicMax(reinterpret_cast<unsigned int*>(mx_slot), __float_as_uint(v));
+  } else if (c < n0) {
+    dst0[c] += v;
+  } else {
+    dst1[c - n0] += v;
   }
 }
 
@@ -304,21 +399,35 @@ __global__ void k_nerf_wd_column(const float* __restrict__ wd, float* __restrict
   for (int c = 257; c < 288; ++c) w7t[(size_t)k * 288 + c] = 0.f;
 }
 
-// dHsum[r][j] = sum over the S samples of ray r of dH[m][j] ; 4 wavefront pairs per ray walk every 4th sample
+// dHsum[r][j] = sum over the S samples of ray r of dH[m][j] ; 4 wavefront pairs per ray walk every 4th sample; a work-group takes
+// every gridDim.x-th ray and records its maximum once
 __global__ __launch_bounds__(512) void k_nerf_ray_sum(const float* __restrict__ dH, int R, int S, float* __restrict__ out,
                                                       float* __restrict__ mx_sum) {
   __shared__ float red[4][128];
-  const int r = blockIdx.x, j = threadIdx.x & 127, q = threadIdx.x >> 7;
-  float acc = 0.f;
-  const float* p = dH + (size_t)r * S * 128 + j;
-  for (int s = q; s < S; s += 4) acc += p[(size_t)s * 128];
-  red[q][j] = acc;
-  __syncthreads();
-  if (q == 0) {
-    acc = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
-    out[(size_t)r * 128 + j] = acc;
-    if (mx_sum) pp_record_max(mx_sum, fabsf(acc));
+  __shared__ float redm[2];
+  const int j = threadIdx.x & 127, q = threadIdx.x >> 7;
+  float vmax = 0.f;
+  for (int r = blockIdx.x; r < R; r += gridDim.x) {
+    float acc = 0.f;
+    const float* p = dH + (size_t)r * S * 128 + j;
+#pragma unroll 8
+    for (int s = q; s < S; s += 4) acc += p[(size_t)s * 128];
+    red[q][j] = acc;
+    __syncthreads();
+    if (q == 0) {
+      acc = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+      out[(size_t)r * 128 + j] = acc;
+      vmax = fmaxf(vmax, fabsf(acc));
+    }
+    __syncthreads();
   }
+  if (mx_sum && q == 0) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = vmax;
+  }
+  __syncthreads();
+  if (mx_sum && threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int*>(mx_sum), __float_as_uint(fmaxf(redm[0], redm[1])));
 }
 
 // ------------------------------------------------------------------------------------------------ compositing
@@ -648,7 +757,7 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
     J.src[7] = params + L.wd; J.n[7] = 257 * 256;
     J.src[8] = params + L.r0; J.n[8] = 128 * 288;
     hipLaunchKernelGGL(k_nerf_wmax, dim3(32, 9), dim3(256), 0, st, J, mx);
-    hipLaunchKernelGGL(k_nerf_enc_bound, dim3(pp_div_up(n_rays, 4)), dim3(256), 0, st, center, ray, depth, n_rays, n_samples, mx);
+    hipLaunchKernelGGL(k_nerf_enc_bound, dim3(n_rays < 256 ? pp_div_up(n_rays, 4) : 64), dim3(256), 0, st, center, ray, depth, n_rays, n_samples, mx);
     if (NERF_PLANES) {
       PlanePackJobs P;
       P.n = 8;
@@ -658,7 +767,7 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
       hipLaunchKernelGGL(k_pack_planes, dim3(16, 8), dim3(256), 0, st, P, mx);
     }
   }
-  hipLaunchKernelGGL(k_nerf_encode, dim3(pp_div_up(M, 4)), dim3(256), 0, st, center, ray, depth, bands, M,
+  hipLaunchKernelGGL(k_nerf_encode, dim3(pp_div_up(M, 16)), dim3(256), 0, st, center, ray, depth, bands, M,
                      n_samples, A.enc, A.a[3], A.a[7]);
   const float* in = A.enc;
   for (int l = 0; l < 8; ++l) {
@@ -702,6 +811,7 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
   }
   float* R0T = WT[7] + 256 * 288;                  // [288][128]
   _Float16* r0t_img = reinterpret_cast<_Float16*>(wt + NERF_WT_FLOATS);
+  float* part = wt + NERF_WT_FLOATS + NERF_WTIMG_FLOATS;      // [NERF_PART_WGS][NERF_PART_LD]
   _Float16* wt7_img = r0t_img + 2 * 256 * 128;
   _Float16* wt_img[7];
   for (int l = 1; l <= 6; ++l) wt_img[l] = wt7_img + 2 * 256 * 288 + (size_t)(l - 1) * 2 * 256 * 256;
@@ -734,17 +844,25 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
 
   // colour head
   float* dH = Q;                                   // [M][128]
-  hipLaunchKernelGGL(k_nerf_rgb_bwd, dim3(pp_div_up(M, NERF_STRIP)), b, 0, st, params + L.r1, A.h, rgb_samples, g_rgb_samples,
-                     M, dH, params_grad + L.r1, params_grad + L.br1, slot(MX_DH));
+  {
+    const int wgs = min(pp_div_up(M, NERF_STRIP), NERF_PART_WGS);
+    hipLaunchKernelGGL(k_nerf_rgb_bwd, dim3(wgs), dim3(512), 0, st, params + L.r1, A.h, rgb_samples, g_rgb_samples, M, dH, part);
+    hipLaunchKernelGGL(k_nerf_part_finish, dim3(pp_div_up(388, 64)), dim3(1024), 0, st, part, wgs, params_grad + L.r1, 384, params_grad + L.br1, 3,
+                       slot(MX_DH));
+  }
   nerf_gemm_tn(st, dH, 128, 128, A.a[7], 288, 288, params_grad + L.r0, params_grad + L.br0, count, M, slot(MX_DH), slot(MX_A0 + 7));
-  hipLaunchKernelGGL(k_nerf_ray_sum, dim3(R), dim3(512), 0, st, dH, R, S, dHsum, slot(MX_DHSUM));
+  hipLaunchKernelGGL(k_nerf_ray_sum, dim3(R < 512 ? R : 512), dim3(512), 0, st, dH, R, S, dHsum, slot(MX_DHSUM));
   nerf_gemm<EPI_PLAIN>(st, dHsum, 128, R0T + 256 * 128, 128, 128, 32, nullptr, nullptr, 0, dView, 32, count, R, slot(MX_DHSUM),
                        slot(MX_R0), nullptr);
   // last feature layer: columns 0..255 through the colour head, column 256 from the density
   nerf_gemm<EPI_MASK>(st, dH, 128, R0T, 128, 128, 256, nullptr, A.a[7], 288, P, 288, count, M, slot(MX_DH), slot(MX_R0),
                       slot(MX_P), A.bits[7], planes ? r0t_img : nullptr);
-  hipLaunchKernelGGL(k_nerf_density_bwd, dim3(pp_div_up(M, NERF_DSTRIP)), dim3(1024), 0, st, A.a[6], A.raw, g_density_samples, M, P,
-                     params_grad + L.wd, params_grad + L.bd, slot(MX_P));
+  {
+    const int wgs = min(pp_div_up(M, NERF_DSTRIP), NERF_PART_WGS);
+    hipLaunchKernelGGL(k_nerf_density_bwd, dim3(wgs), dim3(512), 0, st, A.a[6], A.raw, g_density_samples, M, P, part);
+    hipLaunchKernelGGL(k_nerf_part_finish, dim3(pp_div_up(258, 64)), dim3(1024), 0, st, part, wgs, params_grad + L.wd, 256, params_grad + L.bd, 1,
+                       slot(MX_P));
+  }
   nerf_gemm_tn(st, P, 288, 256, A.a[6], 256, 256, params_grad + L.w[7], params_grad + L.b[7], count, M, slot(MX_P), slot(MX_A0 + 6));
   nerf_gemm<EPI_MASK>(st, P, 288, WT[7], 288, 288, 256, nullptr, A.a[6], 256, Q, 256, count, M, slot(MX_P), slot(MX_W0 + 7),
                       slot(MX_DY6), A.bits[6], planes ? wt7_img : nullptr);
