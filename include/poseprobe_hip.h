@@ -426,6 +426,15 @@ int pp_nerf_composite_bwd(const float* rgb_samples, const float* density_samples
                           const float* g_depth, const float* g_opacity, const float* g_weights, float* g_rgb_samples,
                           float* g_density_samples, float* g_ray, void* stream);
 
+/* BARF coarse-to-fine band weights on the device (frequency_nerf.py:250-253): bands[l_3d + l_view] from the device scalar
+ * `progress` - the schedule costs one launch and no host synchronisation.  width = end - start of opt.barf_c2f, formed in double
+ * by the caller and rounded once (what torch does with the Python scalar). */
+int pp_nerf_band_weights(const float* progress, float start, float width, int32_t l_3d, int32_t l_view, float* bands, void* stream);
+/* Photometric loss of the scene branch (base_losses.py:155-156, :304-307): loss[0] = weight * huber_loss(pred, label, delta,
+ * 'mean') over n floats, g_pred[n] = d loss / d pred.  Deterministic (one work-group, fixed summation order). */
+int pp_nerf_huber_loss(const float* pred, const float* label, int32_t n, float delta, float weight, float* loss, float* g_pred,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

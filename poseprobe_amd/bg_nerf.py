@@ -266,13 +266,24 @@ class NeRF(torch.nn.Module):
         counter sees) so the schedule never forces a host synchronisation; same elementwise op order as the reference."""
         dev = self.flat.device
         if self.opt.barf_c2f is None:
-            return torch.ones(14, dtype=torch.float32, device=dev)
+            if getattr(self, '_band_ones', None) is None:
+                self._band_ones = torch.ones(14, dtype=torch.float32, device=dev)
+            return self._band_ones
+        start, end = self.opt.barf_c2f
+        if dev.type == 'cuda':
+            # one launch (pp_nerf_band_weights); a ring of outputs, because a pending autograd backward may still hold the
+            # weights of an earlier forward while `progress` moves on
+            if getattr(self, '_band_ring', None) is None:
+                self._band_ring, self._band_i = torch.empty(16, 14, dtype=torch.float32, device=dev), 0
+            out = self._band_ring[self._band_i]
+            self._band_i = (self._band_i + 1) % 16
+            ops.nerf_band_weights(self.progress.data, float(start), float(end), self.L_3D, self.L_VIEW, out)
+            return out
         if getattr(self, '_band_consts', None) is None:
             L = torch.tensor([float(self.L_3D)] * self.L_3D + [float(self.L_VIEW)] * self.L_VIEW, device=dev)
             k = torch.tensor(list(range(self.L_3D)) + list(range(self.L_VIEW)), dtype=torch.float32, device=dev)
             self._band_consts = (L, k)
         L, k = self._band_consts
-        start, end = self.opt.barf_c2f
         alpha = (self.progress.data - start) / (end - start) * L
         return (1 - (alpha - k).clamp_(min=0, max=1).mul_(math.pi).cos_()) / 2
 
@@ -477,17 +488,19 @@ class SceneEngine:
                                 d=torch.empty(R, **f), op=torch.empty(R, **f), w=torch.empty(R, S, **f), cum=torch.empty(R, **f),
                                 rv=torch.empty(R, **f), dv=torch.empty(R, **f), g_rgb_s=torch.empty(R * S, 3, **f),
                                 g_dens=torch.empty(R * S, **f), g_ray_c=torch.empty(R, 3, **f), g_center=torch.empty(R, 3, **f),
-                                g_ray=torch.empty(R, 3, **f), zero_r=torch.zeros(R, **f))
+                                g_ray=torch.empty(R, 3, **f), zero_r=torch.zeros(R, **f), g_rgb=torch.empty(R, 3, **f),
+                                loss=torch.zeros(256, **f), loss_i=-1)
         b = ws.step_bufs
         white = bool(net.opt.nerf.setbg_opaque or net.opt.mask_img)
         ops.nerf_fwd(net.flat, center, ray, depth, net.band_weights(), ws.count, R, S, ws.acts, b['rgb_s'], b['dens'])
         ops.nerf_composite_fwd(b['rgb_s'], b['dens'], depth, ray, R, S, white, b['rgb'], b['d'], b['op'], b['w'], b['cum'],
                                b['rv'], b['dv'])
-        diff = b['rgb'] - image                                   # tiny, per-ray: the loss and its gradient on [R,3] colours
-        ad = diff.abs()
-        loss = 2. * torch.where(ad <= 0.5, 0.5 * diff * diff, 0.5 * (ad - 0.25)).mean()
-        g_rgb = (2. / diff.numel()) * diff.clamp(-0.5, 0.5)
-        ops.nerf_composite_bwd(b['rgb_s'], b['dens'], depth, ray, b['w'], R, S, white, g_rgb.contiguous(), b['zero_r'],
+        # 2 * huber(delta = 0.5, mean) and its gradient on the [R,3] colours in one launch; the loss lands in a ring slot (the
+        # returned 0-dim tensor is rewritten 256 passes later: read it - .item() / copy - before that)
+        b['loss_i'] = (b['loss_i'] + 1) % 256
+        loss = b['loss'][b['loss_i']]
+        ops.nerf_huber_loss(b['rgb'], image.contiguous(), 0.5, 2.0, loss, b['g_rgb'])
+        ops.nerf_composite_bwd(b['rgb_s'], b['dens'], depth, ray, b['w'], R, S, white, b['g_rgb'], b['zero_r'],
                                b['zero_r'], None, b['g_rgb_s'], b['g_dens'], b['g_ray_c'])
         ops.nerf_bwd(net.flat, ray, depth, ws.count, R, S, ws.acts, b['rgb_s'], b['g_rgb_s'], b['g_dens'], ws.scratch,
                      state.grad, b['g_center'], b['g_ray'])

@@ -890,6 +890,62 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
   return PP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ schedule + photometric loss
+// The pieces of a scene-branch step that are a dozen one-line elementwise launches in torch (4.6 us of stream time each).
+
+// BARF coarse-to-fine weights of the point bands then the view bands (frequency_nerf.py:250-253), same op order:
+// alpha = (progress - start) / (end - start) * L ; w_k = (1 - cos(clamp(alpha - k, 0, 1) * pi)) / 2 ; `width` = end - start formed
+// by the caller in double and rounded once, as torch rounds the Python scalar
+__global__ void k_nerf_band_weights(const float* __restrict__ progress, float start, float width, int L3, int LV,
+                                    float* __restrict__ bands) {
+  const int i = threadIdx.x;
+  if (i >= L3 + LV) return;
+  const int L = i < L3 ? L3 : LV, k = i < L3 ? i : i - L3;
+  const float alpha = (progress[0] - start) / width * (float)L;
+  const float c = fminf(fmaxf(alpha - (float)k, 0.f), 1.f) * NERF_PI;
+  bands[i] = (1.f - cosf(c)) / 2.f;
+}
+
+extern "C" int pp_nerf_band_weights(const float* progress, float start, float width, int32_t l_3d, int32_t l_view, float* bands,
+                                    void* stream) {
+  PP_REQUIRE(progress && bands, "null pointer");
+  PP_REQUIRE(l_3d >= 0 && l_view >= 0 && l_3d + l_view > 0 && l_3d + l_view <= 64 && width != 0.f, "bad arguments");
+  hipLaunchKernelGGL(k_nerf_band_weights, dim3(1), dim3(64), 0, pp_stream(stream), progress, start, width, l_3d, l_view, bands);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+// weight * huber_loss(pred, label, delta, reduction = mean) and its gradient w.r.t. pred (base_losses.py:155-156: delta = 0.5,
+// weight = 2).  One work-group, fixed summation order (strided partial sums, then a tree over the 1024 partials).
+__global__ __launch_bounds__(1024) void k_nerf_huber(const float* __restrict__ pred, const float* __restrict__ label, int n,
+                                                     float delta, float weight, float* __restrict__ loss,
+                                                     float* __restrict__ g_pred) {
+  __shared__ float red[1024];
+  float acc = 0.f;
+  const float gs = weight / (float)n;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float d = pred[i] - label[i], ad = fabsf(d);
+    acc += ad <= delta ? 0.5f * d * d : delta * (ad - 0.5f * delta);
+    g_pred[i] = gs * fminf(fmaxf(d, -delta), delta);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = weight * (red[0] / (float)n);
+}
+
+extern "C" int pp_nerf_huber_loss(const float* pred, const float* label, int32_t n, float delta, float weight, float* loss,
+                                  float* g_pred, void* stream) {
+  PP_REQUIRE(pred && label && loss && g_pred, "null pointer");
+  PP_REQUIRE(n > 0 && delta > 0.f, "bad arguments");
+  hipLaunchKernelGGL(k_nerf_huber, dim3(1), dim3(1024), 0, pp_stream(stream), pred, label, n, delta, weight, loss, g_pred);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
 extern "C" int pp_nerf_composite_fwd(const float* rgb_samples, const float* density_samples, const float* depth,
                                      const float* ray, int32_t n_rays, int32_t n_samples, int32_t white_bg, float* rgb,
                                      float* depth_out, float* opacity, float* weights, float* all_cumulated, float* rgb_var,

@@ -390,3 +390,14 @@ def nerf_composite_bwd(rgb_samples, density_samples, depth, ray, weights, n_rays
     _lib.call('pp_nerf_composite_bwd', _f(rgb_samples), _f(density_samples), _f(depth), _f(ray), _f(weights), int(n_rays),
               int(n_samples), int(bool(white_bg)), _f(g_rgb), _f(g_depth), _f(g_opacity), _f(g_weights), _f(g_rgb_samples),
               _f(g_density_samples), _f(g_ray), _stream())
+
+
+def nerf_band_weights(progress, start, end, l_3d, l_view, bands):
+    _lib.call('pp_nerf_band_weights', _f(progress), ctypes.c_float(start), ctypes.c_float(float(end) - float(start)), int(l_3d), int(l_view), _f(bands),
+              _stream())
+
+
+def nerf_huber_loss(pred, label, delta, weight, loss, g_pred):
+    """loss[0] = weight * huber(pred, label, delta, mean); g_pred = its gradient (base_losses.py:155-156)."""
+    _lib.call('pp_nerf_huber_loss', _f(pred), _f(label), int(pred.numel()), ctypes.c_float(delta), ctypes.c_float(weight), _f(loss),
+              _f(g_pred), _stream())

@@ -613,3 +613,34 @@ def test_depth_consistency_loss_through_the_hip_render_path():
     bottom = torch.tensor([[0., 0., 0., 1.]]).cuda()
     z, _ = bg_losses.depth_consistency_loss_at_pose(sr, opt, torch.cat([poses[0].detach(), bottom]), intr[0], far, H, W, 0.5, 900)
     assert float(z) == 0.0 and z.requires_grad
+
+
+def test_photometric_loss_kernel_equals_torch_huber():
+    """pp_nerf_huber_loss = 2 * F.huber_loss(delta = 0.5, mean) and its gradient (base_losses.py:155-156), both branches, odd sizes."""
+    from poseprobe_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for n in (3, 3069, 40000):
+        pred = (torch.rand(n, generator=g) * 2.0 - 0.5).cuda().requires_grad_(True)       # residuals on both sides of delta
+        label = torch.rand(n, generator=g).cuda()
+        ref = torch.nn.functional.huber_loss(pred, label, reduction='mean', delta=0.5) * 2.
+        ref.backward()
+        loss, gp = torch.zeros(1, device='cuda'), torch.empty(n, device='cuda')
+        ops.nerf_huber_loss(pred.detach(), label, 0.5, 2.0, loss, gp)
+        assert_close(loss[0], ref.detach(), rtol=2e-6, name=f'huber[{n}]')
+        assert_close(gp, pred.grad, rtol=1e-6, atol=1e-12, name=f'huber grad[{n}]')
+
+
+def test_band_weight_kernel_equals_the_torch_expression():
+    """pp_nerf_band_weights against frequency_nerf.py:250-253 evaluated by torch on the device, before / inside / after the window."""
+    import math
+    from poseprobe_amd import ops
+    out = torch.empty(14, device='cuda')
+    for p in (0.0, 0.4, 0.4375, 0.565, 0.7, 1.0):
+        prog = torch.tensor(p, device='cuda')
+        ops.nerf_band_weights(prog, 0.4, 0.7, 10, 4, out)
+        ref = []
+        for L in (10, 4):
+            alpha = (prog - 0.4) / (0.7 - 0.4) * L
+            k = torch.arange(L, dtype=torch.float32, device='cuda')
+            ref.append((1 - (alpha - k).clamp_(min=0, max=1).mul_(math.pi).cos_()) / 2)
+        assert_close(out, torch.cat(ref), rtol=0, atol=1.2e-7, name=f'bands at {p}')
