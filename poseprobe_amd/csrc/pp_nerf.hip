@@ -592,19 +592,24 @@ __global__ __launch_bounds__(256) void k_nerf_encode_bwd(const float* __restrict
     sgn = (s == 0) ? 1 : -1;
     partner = (s == 0) ? j + NERF_L3D : j - NERF_L3D;
   }
-  float gc[3] = {0.f, 0.f, 0.f}, gr[3] = {0.f, 0.f, 0.f};
+  // a lane sums ITS element's contributions over the samples it meets (d/d center) and the depth-weighted ones (d/d ray); the
+  // three per-coordinate sums over the lanes are formed once per wavefront at the end, not once per sample
+  float lc = 0.f, lr = 0.f;
+#pragma unroll 4
   for (int s = wid; s < S; s += 4) {
     const size_t m = (size_t)r * S + s;
     const float g = dEnc0[m * 64 + j] + dEncS[m * 64 + j];
     const float e = enc[m * 64 + j];
     const float ep = __shfl(e, partner, 64);
     const float contrib = (j < 3) ? g : (float)sgn * f * ep * g;
-    const float p0 = pp_wave_sum(c == 0 ? contrib : 0.f);
-    const float p1 = pp_wave_sum(c == 1 ? contrib : 0.f);
-    const float p2 = pp_wave_sum(c == 2 ? contrib : 0.f);
-    const float t = depth[m];
-    gc[0] += p0; gc[1] += p1; gc[2] += p2;
-    gr[0] += t * p0; gr[1] += t * p1; gr[2] += t * p2;
+    lc += contrib;
+    lr += depth[m] * contrib;
+  }
+  float gc[3], gr[3];
+#pragma unroll
+  for (int cc = 0; cc < 3; ++cc) {
+    gc[cc] = pp_wave_sum(c == cc ? lc : 0.f);
+    gr[cc] = pp_wave_sum(c == cc ? lr : 0.f);
   }
   if (j == 0) { for (int i = 0; i < 3; ++i) { red[wid][i] = gc[i]; red[wid][3 + i] = gr[i]; } }
   __syncthreads();
