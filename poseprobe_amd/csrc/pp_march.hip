@@ -5,6 +5,15 @@
 // coalesced (the reference walks each ray from a single thread).
 #include "pp_common.h"
 
+// value of lane j (j wave-uniform): v_readlane_b32 instead of the ds_bpermute_b32 that __shfl compiles to - inside the sequential
+// loops below an LDS crossbar round trip per sample was most of the iteration (k_march_fwd 17.6 us for a 186-sample ray)
+__device__ __forceinline__ float lane_value(float v, int j) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+__device__ __forceinline__ double lane_value(double v, int j) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j), __builtin_amdgcn_readlane(__double2loint(v), j));
+}
+
 template <bool FUSED, bool DVGO>
 __global__ __launch_bounds__(256) void k_march_fwd(const float* __restrict__ alpha, const float* __restrict__ rgb,
                                                    const float* __restrict__ step_w, const float* __restrict__ nrm_in,
@@ -14,7 +23,7 @@ __global__ __launch_bounds__(256) void k_march_fwd(const float* __restrict__ alp
                                                    float* __restrict__ rgb_marched, float* __restrict__ rgb_pre,
                                                    float* __restrict__ cum_weights, float* __restrict__ depth_acc,
                                                    float* __restrict__ normal_marched) {
-  int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: the loop control below is scalar
   int lane = threadIdx.x & 63;
   if (r >= n_rays) return;
   const int b = ray_start[r], e = ray_start[r + 1];
@@ -22,31 +31,46 @@ __global__ __launch_bounds__(256) void k_march_fwd(const float* __restrict__ alp
   int stop = e;            // absolute index one past the last sample that received a weight
   bool stopped = false;
   float acc_rgb[3] = {0, 0, 0}, acc_w = 0.f, acc_d = 0.f, acc_n[3] = {0, 0, 0};
+  float a_next = (b + lane < e) ? alpha[b + lane] : 0.f;
   for (int c0 = b; c0 < e; c0 += 64) {
     int i = c0 + lane;
-    float a = (i < e) ? alpha[i] : 0.f;
+    const float a = a_next;
+    // everything the chunk needs from memory is requested before the sequential loop (and the next chunk's alpha with it): the
+    // loop is ~100 ns per sample of pure latency, the loads land underneath it
+    a_next = (i + 64 < e) ? alpha[i + 64] : 0.f;
+    float cr[3] = {0.f, 0.f, 0.f}, cs = 0.f, cn[3] = {0.f, 0.f, 0.f};
+    if (FUSED && i < e) {
+      if (rgb) for (int k = 0; k < 3; ++k) cr[k] = rgb[i * 3 + k];
+      if (step_w) cs = step_w[i];
+      if (nrm_in) for (int k = 0; k < 3; ++k) cn[k] = nrm_in[i * 3 + k];
+    }
     float myT = 1.f, myw = 0.f;
     if (!stopped) {
       int n = e - c0 < 64 ? e - c0 : 64;
+      // the transmittance is a sequential product; a sample's factor (1 - alpha, in double for the reference's arithmetic) is
+      // formed by its own lane before the loop, and its weight T * alpha after it: the serial part is one multiply per sample
+      const double omd = 1.0 - (double)a;
+      const float omf = fmaxf(1.f - a, 1e-10f);
+      bool reached = false;
       for (int j = 0; j < n; ++j) {
-        float aj = __shfl(a, j, 64);
-        if (lane == j) { myT = Tc; myw = Tc * aj; }
+        if (lane == j) { myT = Tc; reached = true; }
         if (DVGO) {           // cumprod_exclusive: p.clamp_min(1e-10).cumprod(-1), fp32, no early stop (dvgo_ori.py:478-485)
-          Tc = Tc * fmaxf(1.f - aj, 1e-10f);
+          Tc = Tc * lane_value(omf, j);
         } else {
-          Tc = (float)((double)Tc * (1.0 - (double)aj));
-          if ((double)Tc < 1e-3) { stop = c0 + j + 1; stopped = true; break; }
+          Tc = (float)((double)Tc * lane_value(omd, j));
+          if (Tc < 1e-3f) { stop = c0 + j + 1; stopped = true; break; }   // == ((double)Tc < 1e-3): float(1e-3) is the first float above it
         }
       }
+      if (reached) myw = myT * a;
     }
     if (i < e) {
       weights[i] = myw;
       if (Tout) Tout[i] = myT;
       if (FUSED) {
         acc_w += myw;
-        if (rgb) for (int k = 0; k < 3; ++k) acc_rgb[k] += myw * rgb[i * 3 + k];
-        if (step_w) acc_d += myw * step_w[i];
-        if (nrm_in) for (int k = 0; k < 3; ++k) acc_n[k] += myw * nrm_in[i * 3 + k];
+        if (rgb) for (int k = 0; k < 3; ++k) acc_rgb[k] += myw * cr[k];
+        if (step_w) acc_d += myw * cs;
+        if (nrm_in) for (int k = 0; k < 3; ++k) acc_n[k] += myw * cn[k];
       }
     }
   }
@@ -81,7 +105,7 @@ __global__ __launch_bounds__(256) void k_march_bwd(const float* __restrict__ alp
                                                    const float* __restrict__ g_last, const float* __restrict__ g_depth,
                                                    const float* __restrict__ g_w_in, float* __restrict__ g_alpha,
                                                    float* __restrict__ g_rgb) {
-  int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
   if (r >= n_rays) return;
   const int b = ray_start[r], e = ray_start[r + 1], stop = i_end[r];
@@ -97,29 +121,53 @@ __global__ __launch_bounds__(256) void k_march_bwd(const float* __restrict__ alp
   }
   float back = (g_last ? g_last[r] : 0.f) * alphainv_last[r];
   int nchunk = (e - b + 63) / 64;
+  // a chunk's operands are requested one chunk ahead, so that they land under the sequential loop of the chunk before
+  struct Chunk { float a, w, T, gw, v[3], sw; };
+  auto fetch = [&](int c) {
+    Chunk k;
+    const int i = b + c * 64 + lane;
+    const bool live = i < e;
+    k.a = live ? alpha[i] : 0.f;
+    k.w = live ? weights[i] : 0.f;
+    k.T = live ? Tin[i] : 1.f;
+    k.gw = (live && g_w_in) ? g_w_in[i] : 0.f;
+    k.v[0] = k.v[1] = k.v[2] = 0.f; k.sw = 0.f;
+    if (FUSED && live) {
+      if (rgb) for (int q = 0; q < 3; ++q) k.v[q] = rgb[i * 3 + q];
+      if (step_w) k.sw = step_w[i];
+    }
+    return k;
+  };
+  Chunk nx = fetch(nchunk > 0 ? nchunk - 1 : 0);
   for (int c = nchunk - 1; c >= 0; --c) {
     int c0 = b + c * 64;
     int i = c0 + lane;
     bool live = i < e;
-    float a = live ? alpha[i] : 0.f;
-    float w = live ? weights[i] : 0.f;
-    float T = live ? Tin[i] : 1.f;
-    float gw = (live && g_w_in) ? g_w_in[i] : 0.f;
+    const Chunk ck = nx;
+    if (c > 0) nx = fetch(c - 1);
+    const float a = ck.a, w = ck.w, T = ck.T;
+    float gw = ck.gw;
     if (FUSED && live) {
       float wr = 0.f;
-      if (rgb) for (int k = 0; k < 3; ++k) { float v = rgb[i * 3 + k]; wr += gm[k] * v; if (g_rgb) g_rgb[i * 3 + k] = w * gm[k]; }
-      gw += wr + gcw + (step_w ? gd * step_w[i] : 0.f);
+      if (rgb) for (int k = 0; k < 3; ++k) { wr += gm[k] * ck.v[k]; if (g_rgb) g_rgb[i * 3 + k] = w * gm[k]; }
+      gw += wr + gcw + (step_w ? gd * ck.sw : 0.f);
     }
-    float ga = 0.f;
     int hi = stop - c0;           // samples [c0, stop) of this chunk take part
     if (hi > 64) hi = 64;
+    // the running sum `back` is sequential (fp32, last sample first); everything else of a sample's gradient - the double-precision
+    // division included - only needs the value `back` had when the sequence reached it: the serial loop is one add per sample and
+    // hands lane j its value, the rest is evaluated by all lanes at once (same operations per sample, same results)
+    const float gww = gw * w;
+    float myback = 0.f;
     for (int j = hi - 1; j >= 0; --j) {
-      float gwj = __shfl(gw, j, 64), aj = __shfl(a, j, 64), wj = __shfl(w, j, 64), Tj = __shfl(T, j, 64);
-      float gwT = gwj * Tj;
-      double denom = (double)(1.f - aj) + 1e-10;
-      float g = (float)((double)gwT - (double)back / denom);
-      if (lane == j) ga = g;
-      back += gwj * wj;
+      if (lane == j) myback = back;
+      back += lane_value(gww, j);
+    }
+    float ga = 0.f;
+    if (lane < hi) {
+      const float gwT = gw * T;
+      const double denom = (double)(1.f - a) + 1e-10;
+      ga = (float)((double)gwT - (double)myback / denom);
     }
     if (live) g_alpha[i] = ga;
   }
