@@ -226,7 +226,8 @@ int pp_context_join(void* ctx, void* stream);
  * rgbnet (voxurf_coarse.py:208-216, :1032-1033): 64(57)->128->128->128->3, sigmoid.
  * Parameter block layout (floats): W0[128*64] b0[128] W1[128*128] b1[128] W2[128*128] b2[128] W3[3*128] b3[3]
  * (W0 is the reference's [128,57] weight zero-padded to 64 columns).
- * acts[3][cap][128] keeps the hidden activations for the backward. */
+ * acts[3][cap][128] keeps the hidden activations for the backward; acts = NULL: forward only (inference), nothing is kept -
+ * accepted with the default split-precision forward kernel (option mlp_split bit 4), refused otherwise. */
 #define PP_RGBNET_PARAMS (128 * 64 + 128 + 2 * (128 * 128 + 128) + 3 * 128 + 3)
 int pp_rgbnet_fwd(const float* params, const float* feat, const int32_t* count, int32_t capacity, float* acts,
                   float* rgb, void* stream);
@@ -238,7 +239,7 @@ int pp_rgbnet_bwd(const float* params, const float* feat, const float* acts, con
  * evaluated together with its input Jacobian in forward mode (row 0 primal, rows 1-3 tangents), which
  * replaces the reference's three autograd.grad(create_graph=True) passes (voxurf_coarse.py:972-984).
  * Parameter block: W0[128*3] b0[128] W1..W3[128*128]+b[128] each, W4[4*128] b4[4].
- * acts[4][cap*4][128]; out[M,4,4] (x out_range). */
+ * acts[4][cap*4][128] (NULL: forward only, as for pp_rgbnet_fwd; option mlp_split bit 1); out[M,4,4] (x out_range). */
 #define PP_WARP_PARAMS (128 * 3 + 128 + 3 * (128 * 128 + 128) + 4 * 128 + 4)
 int pp_warp_fwd(const float* params, const float* pts, const int32_t* count, int32_t capacity, float out_range,
                 float* acts, float* out, void* stream);

@@ -351,8 +351,11 @@ static inline size_t mlp_off_out(int in_ld, int n_gemm) { return mlp_off_hidden(
 extern "C" int pp_mlp_fwd(const float* params, const float* feat, int32_t in_ld, int32_t n_gemm, const int32_t* count,
                           int32_t capacity, const float* logit_add, int32_t logit_add_ld, float* acts, float* out,
                           void* stream) {
-  PP_REQUIRE(params && feat && count && acts && out, "null pointer");
+  PP_REQUIRE(params && feat && count && out, "null pointer");
   PP_REQUIRE(capacity > 0 && in_ld % 32 == 0 && in_ld <= 128 && n_gemm >= 1 && n_gemm <= 8, "bad sizes");
+  // acts == NULL: forward only (no backward pass will follow: the activations are not written) - the split-precision fused kernel only
+  PP_REQUIRE(acts || (in_ld == 64 && n_gemm == 3 && mlp_fused_enabled() && (pp_opt(PP_OPT_MLP_SPLIT) & 4)),
+             "acts may be NULL only for the rgbnet shape with the split-precision forward kernel (option mlp_split bit 4)");
   hipStream_t st = pp_stream(stream);
   if (in_ld == 64 && n_gemm == 3 && mlp_fused_enabled()) {       // the Voxurf rgbnet shape: layer-fused kernel
     if (pp_opt(PP_OPT_MLP_SPLIT) & 4) pp_launch_rgb_fused_fwd_s(params, feat, count, capacity, logit_add, logit_add_ld, acts, out, st);
@@ -450,8 +453,10 @@ extern "C" int pp_rgbnet_bwd(const float* params, const float* feat, const float
 
 extern "C" int pp_warp_fwd(const float* params, const float* pts, const int32_t* count, int32_t capacity,
                            float out_range, float* acts, float* out, void* stream) {
-  PP_REQUIRE(params && pts && count && acts && out, "null pointer");
+  PP_REQUIRE(params && pts && count && out, "null pointer");
   PP_REQUIRE(capacity > 0, "capacity<=0");
+  PP_REQUIRE(acts || (mlp_fused_enabled() && (pp_opt(PP_OPT_MLP_SPLIT) & 1)),
+             "acts may be NULL (forward only) only with the split-precision forward kernel (option mlp_split bit 1)");
   hipStream_t st = pp_stream(stream);
   if (mlp_fused_enabled()) {
     if (pp_opt(PP_OPT_MLP_SPLIT) & 1) pp_launch_warp_fused_fwd_s(params, pts, count, capacity, out_range, acts, out, st);

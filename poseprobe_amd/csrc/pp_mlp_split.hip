@@ -354,8 +354,9 @@ __global__ __launch_bounds__(256) void k_warp_fused_fwd_s(const float* __restric
       pnext = 0.f;
       if (tid < 48 && nt < ntiles && nt * 48 + tid < M * 3) pnext = pts[nt * 48 + tid];
     }
-    const bool ok0 = r0 + l31 < R, ok1 = r0 + 32 + l31 < R;
-    float* __restrict__ crow = acts + (size_t)(r0 + l31) * 128 + fb;           // this lane's row of half 0 in X0
+    // acts == nullptr: forward only (inference) - the activations are not written
+    const bool ok0 = acts != nullptr && r0 + l31 < R, ok1 = acts != nullptr && r0 + 32 + l31 < R;
+    float* __restrict__ crow = acts + (acts != nullptr ? (size_t)(r0 + l31) * 128 + fb : 0);   // this lane's row of half 0 in X0
     _Float16* const arow0 = &At[0][l31 * LDH2 + fb];                            // ... in LDS tile 0 / 1
     _Float16* const arow1 = &At[1][l31 * LDH2 + fb];
     float* const frow1 = reinterpret_cast<float*>(At[1]) + l31 * LDA + fb;      // fp32 view of tile 1
@@ -989,8 +990,8 @@ __global__ __launch_bounds__(256) void k_rgb_fused_fwd_s(const float* __restrict
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
     const int r0 = tile * TILE_ROWS;
     const int tnext = tile + gridDim.x;
-    const bool ok0 = r0 + l31 < R, ok1 = r0 + 32 + l31 < R;
-    float* __restrict__ crow = acts + (size_t)(r0 + l31) * 128 + fb;
+    const bool ok0 = acts != nullptr && r0 + l31 < R, ok1 = acts != nullptr && r0 + 32 + l31 < R;     // acts == nullptr: forward only
+    float* __restrict__ crow = acts + (acts != nullptr ? (size_t)(r0 + l31) * 128 + fb : 0);
     _Float16* const arow0 = &At[0][l31 * LDH2 + fb];
     _Float16* const arow1 = &At[1][l31 * LDH2 + fb];
     float* const frow0 = reinterpret_cast<float*>(At[0]) + l31 * LDA + fb;      // fp32 view of tile 0

@@ -77,7 +77,7 @@ def dynamic_weight(w0, w1, it, total):
 class Workspace:
     """All per-ray / per-sample device buffers for N rays and `capacity` samples (default N*S)."""
 
-    def __init__(self, N, capacity, device, sample_capacity=None, backward=True):
+    def __init__(self, N, capacity, device, sample_capacity=None, backward=True, keep_activations=True):
         f = dict(dtype=torch.float32, device=device)
         i = dict(dtype=torch.int32, device=device)
         self.N, self.cap = N, capacity
@@ -93,12 +93,16 @@ class Workspace:
         self.pts, self.ray_id, self.step_k, self.step = e(sc_, 3, **f), e(sc_, **i), e(sc_, **i), e(sc_, **f)
         wsz = ops.mlp_workspaces(capacity)                 # sizes come from the library (pp_rgbnet_workspace / pp_warp_workspace)
         assert wsz['warp'][0] == 4 * capacity * 4 * 128 and wsz['rgbnet'][0] == 3 * capacity * 128
-        self.warp_acts = e(4, capacity * 4, 128, **f)
+        # keep_activations=False (inference: nobody will differentiate this pass): the MLP activations are not kept when the forward kernels can run without them
+        # (pp_warp_fwd / pp_rgbnet_fwd with acts = NULL: the split-precision kernels, the default): 2.5 KB per sample less to write
+        from . import _lib
+        split = _lib.get_option('mlp_split') if _lib.get_option('mlp_fused') else 0
+        self.warp_acts = e(4, capacity * 4, 128, **f) if (backward or keep_activations or not split & 1) else None
         self.warp_out = e(capacity, 16, **f)
         self.alpha, self.gradient = e(capacity, **f), e(capacity, 3, **f)
         self.sdf_final, self.sdf_deform, self.grad_deform = e(capacity, **f), e(capacity, **f), e(capacity, 9, **f)
         self.feat = e(capacity, ops.FEAT_LD, **f)
-        self.rgb_acts = e(3, capacity, 128, **f)
+        self.rgb_acts = e(3, capacity, 128, **f) if (backward or keep_activations or not split & 4) else None
         self.rgb = e(capacity, 3, **f)
         self.weights, self.T = e(capacity, **f), e(capacity, **f)
         # ray outputs

@@ -577,7 +577,7 @@ class Voxurf(torch.nn.Module):
         ops.sample_var(cfg.pp, ro, rd, sc, t_min, t_max, n_steps, ray_start, count, pts, ray_id, step_id)
         M = int(count.item())
         cap = max((M + 4095) // 4096 * 4096, 4096)
-        ws = Workspace(N, cap, dev, sample_capacity=sc, backward=False)
+        ws = Workspace(N, cap, dev, sample_capacity=sc, backward=False, keep_activations=False)
         ws.M = M
         ws.rays_o, ws.rays_d, ws.viewdirs = ro, rd, vd
         ws.t_min, ws.t_max, ws.ray_start, ws.count, ws.pts, ws.ray_id, ws.step_k = t_min, t_max, ray_start, count, pts, ray_id, step_id

@@ -249,3 +249,34 @@ def test_weight_gradient_kernels_follow_growing_magnitudes():
         _lib.set_option('mlp_split', default)
     for l, a, b in zip((3, 2, 1), err[0], err[16]):
         assert b <= 1.25 * a + 1e-9 and b < 5e-6, f'W{l} gradient: fp32 chain {a:.3e}, split chain {b:.3e}'
+
+
+def test_forward_only_mode_gives_the_same_outputs_without_keeping_activations():
+    """pp_warp_fwd / pp_rgbnet_fwd with acts = NULL (inference): bit-identical outputs, nothing written; refused by the kernels that
+    cannot run without the buffer."""
+    from poseprobe_amd import ops, _lib
+    g = torch.Generator().manual_seed(7)
+    M, cap = 4099, 4608
+    count = torch.tensor([M], dtype=torch.int32, device='cuda')
+    warp_p = torch.zeros(ops.WARP_PARAMS + 60, device='cuda'); warp_p[:ops.WARP_PARAMS] = (torch.randn(ops.WARP_PARAMS, generator=g) * 0.09).cuda()
+    rgb_p = torch.zeros(ops.RGBNET_PARAMS + 60, device='cuda'); rgb_p[:ops.RGBNET_PARAMS] = (torch.randn(ops.RGBNET_PARAMS, generator=g) * 0.09).cuda()
+    pts = (torch.randn(cap, 3, generator=g) * 0.5).cuda()
+    feat = torch.randn(cap, 64, generator=g).cuda(); feat[:, 57:] = 0
+    acts = torch.empty(4, cap * 4, 128, device='cuda'); racts = torch.empty(3, cap, 128, device='cuda')
+    out_a, out_b = torch.zeros(cap, 16, device='cuda'), torch.zeros(cap, 16, device='cuda')
+    rgb_a, rgb_b = torch.zeros(cap, 3, device='cuda'), torch.zeros(cap, 3, device='cuda')
+    ops.warp_fwd(warp_p, pts, count, cap, 1.5, acts, out_a)
+    ops.warp_fwd(warp_p, pts, count, cap, 1.5, None, out_b)
+    ops.rgbnet_fwd(rgb_p, feat, count, cap, racts, rgb_a)
+    ops.rgbnet_fwd(rgb_p, feat, count, cap, None, rgb_b)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a[:M], out_b[:M]) and torch.equal(rgb_a[:M], rgb_b[:M])
+    old = _lib.get_option('mlp_split')
+    try:
+        _lib.set_option('mlp_split', 0)
+        with pytest.raises(_lib.PoseProbeError):
+            ops.warp_fwd(warp_p, pts, count, cap, 1.5, None, out_b)
+        with pytest.raises(_lib.PoseProbeError):
+            ops.rgbnet_fwd(rgb_p, feat, count, cap, None, rgb_b)
+    finally:
+        _lib.set_option('mlp_split', old)
