@@ -39,7 +39,7 @@ int pp_abi_version(void);
 /* Tuning options: explicit, caller-set, process-wide integers with compiled-in defaults (the measured best on MI355X).
  * The library never reads the environment; the Python host maps PP_* environment variables onto these calls when it
  * loads the library (poseprobe_amd/_lib.py).  Names: mlp_fused, wgrad_split, grid_chunks, nerf_split, nerf_split_tn,
- * nerf_bitmask, nerf_gemm_wgs, nerf_tn_ch, nerf_tn_split_wgs, nerf_tn_wgs, nerf_bn, nerf_planes, sdf_index_exact, mlp_split, nerf_tn256, mlp_wgs (meaning and ranges:
+ * nerf_bitmask, nerf_gemm_wgs, nerf_tn_ch, nerf_tn_split_wgs, nerf_tn_wgs, nerf_bn, nerf_planes, sdf_index_exact, mlp_split, nerf_tn256, mlp_wgs, wgrad_side_wgs (meaning and ranges:
  * csrc/pp_common.h, csrc/pp_error.hip).  Thread-safe (atomic); unknown names / out-of-range values are refused. */
 int pp_set_option(const char* name, int32_t value);
 int pp_get_option(const char* name, int32_t* value);

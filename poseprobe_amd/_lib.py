@@ -80,7 +80,7 @@ def lib():
 # PP_<NAME>=<int> in the environment of the HOST process is applied once, right after loading, through pp_set_option: the
 # switches are the host's, the library itself has no hidden state read from the environment.
 OPTION_NAMES = ('mlp_fused', 'wgrad_split', 'grid_chunks', 'nerf_split', 'nerf_split_tn', 'nerf_bitmask', 'nerf_gemm_wgs',
-                'nerf_tn_ch', 'nerf_tn_split_wgs', 'nerf_tn_wgs', 'nerf_bn', 'nerf_planes', 'sdf_index_exact', 'mlp_split', 'nerf_tn256', 'mlp_wgs')
+                'nerf_tn_ch', 'nerf_tn_split_wgs', 'nerf_tn_wgs', 'nerf_bn', 'nerf_planes', 'sdf_index_exact', 'mlp_split', 'nerf_tn256', 'mlp_wgs', 'wgrad_side_wgs')
 
 
 def _options_from_environment(L):

@@ -30,6 +30,8 @@ enum PPOption {
   PP_OPT_MLP_SPLIT,            // bit mask: layer-fused object-branch MLP kernels with three fp16 products per fp32 product (pp_mlp_split.hip); 1 warp fwd, 2 warp bwd, 4 rgb fwd, 8 rgb bwd, 16 weight-gradient chains
   PP_OPT_NERF_TN256,           // scene branch: 1 = 256 x 256 weight gradients by the one-work-group-per-row-range kernel (pp_gemm_tn256.h; measured equal: 127 vs 123 us)
   PP_OPT_MLP_WGS,              // work-groups of the persistent object-branch MLP kernels (0 = one per CU); fewer leave CUs to a concurrent HBM-bound kernel
+  PP_OPT_WGRAD_SIDE_WGS,       // work-groups of a weight-gradient chain kernel launched on a pp_context's auxiliary stream (0 = as on the main stream):
+                               // fewer leave whole CUs to the small kernels that run beside it
   PP_OPT_COUNT
 };
 int pp_opt(int id);

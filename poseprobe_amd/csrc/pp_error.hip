@@ -25,6 +25,7 @@ static const PPOptionDef g_opt_def[PP_OPT_COUNT] = {
     {"nerf_tn_wgs", 128, 1, 4096}, {"nerf_bn", 128, 128, 256},       {"nerf_planes", 1, 0, 1},
     {"sdf_index_exact", 0, 0, 1},   {"mlp_split", 31, 0, 31},
     {"nerf_tn256", 0, 0, 1},       {"mlp_wgs", 0, 0, 4096},
+    {"wgrad_side_wgs", 0, 0, 4096},
 };
 static std::atomic<int> g_opt[PP_OPT_COUNT];
 static std::atomic<bool> g_opt_init{false};

@@ -396,7 +396,8 @@ extern "C" int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld,
     hipStream_t ws = deferred_fork(ctx, st);
     pp_launch_wgrad_chain(scratch, acts + FLS, params_grad + RGF_W2, scratch + FLS, acts, params_grad + RGF_W1,
                           scratch + 2 * FLS, feat, params_grad + RGF_W0, 64, count, 1, capacity, ws,
-                          sb ? params_grad + RGF_B2 : nullptr, sb ? params_grad + RGF_B1 : nullptr, sb ? params_grad + RGF_B0 : nullptr);
+                          sb ? params_grad + RGF_B2 : nullptr, sb ? params_grad + RGF_B1 : nullptr, sb ? params_grad + RGF_B0 : nullptr,
+                          ws != st ? pp_opt(PP_OPT_WGRAD_SIDE_WGS) : 0);
     deferred_forked(ctx, ws, st);
     PP_CHECK_LAUNCH();
     return PP_OK;
@@ -497,7 +498,8 @@ extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* a
     const bool sb = (pp_opt(PP_OPT_MLP_SPLIT) & 2) != 0;   // the split-precision data-gradient kernel leaves b1..b3 to this one
     pp_launch_wgrad_chain(scratch, acts + 2 * LS, params_grad + WP_W3, scratch + LS, acts + LS, params_grad + WP_W2,
                           scratch + 2 * LS, acts, params_grad + WP_W1, 128, count, 4, rcap, ws,
-                          sb ? params_grad + WP_B3 : nullptr, sb ? params_grad + WP_B2 : nullptr, sb ? params_grad + WP_B1 : nullptr);
+                          sb ? params_grad + WP_B3 : nullptr, sb ? params_grad + WP_B2 : nullptr, sb ? params_grad + WP_B1 : nullptr,
+                          ws != st ? pp_opt(PP_OPT_WGRAD_SIDE_WGS) : 0);
     deferred_forked(ctx, ws, st);
     PP_CHECK_LAUNCH();
     return PP_OK;

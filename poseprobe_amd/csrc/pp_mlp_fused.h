@@ -34,7 +34,7 @@ struct WgradOperands {
 };
 int pp_launch_wgrad_chain_s(const float* YA, const float* XA, float* WA, const float* YB, const float* XB, float* WB,
                             const float* YC, const float* XC, float* WC, int kxc, const int32_t* count, int rmul, int rcap,
-                            hipStream_t st, float* bA, float* bB, float* bC);
+                            hipStream_t st, float* bA, float* bB, float* bC, int wgs = 0);
 // split-precision variants (pp_mlp_split.hip, option "mlp_split"): same contracts
 int pp_launch_warp_fused_fwd_s(const float* params, const float* pts, const int32_t* count, int capacity, float out_range,
                                float* acts, float* out, hipStream_t st);
@@ -46,7 +46,7 @@ int pp_launch_warp_fused_bwd_s(const float* params, const float* pts, const floa
 // form, every fourth row) or over all rows (kxc == 64: rgbnet)
 int pp_launch_wgrad_chain(const float* YA, const float* XA, float* WA, const float* YB, const float* XB, float* WB,
                           const float* YC, const float* XC, float* WC, int kxc, const int32_t* count, int rmul, int rcap,
-                          hipStream_t st, float* bA = nullptr, float* bB = nullptr, float* bC = nullptr);
+                          hipStream_t st, float* bA = nullptr, float* bB = nullptr, float* bC = nullptr, int wgs = 0 /* 0: one per CU */);
 
 // parameter block of rgbnet (64-wide padded input): W0[128x64] b0 | W1[128x128] b1 | W2[128x128] b2 | W3[3x128] b3
 #define RGF_W0 0

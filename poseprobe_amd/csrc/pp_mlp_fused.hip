@@ -780,9 +780,9 @@ static bool wgrad_split_enabled() { return pp_opt(PP_OPT_WGRAD_SPLIT) == 1; }
 
 int pp_launch_wgrad_chain(const float* YA, const float* XA, float* WA, const float* YB, const float* XB, float* WB,
                           const float* YC, const float* XC, float* WC, int kxc, const int32_t* count, int rmul, int rcap,
-                          hipStream_t st, float* bA, float* bB, float* bC) {
+                          hipStream_t st, float* bA, float* bB, float* bC, int wgs) {
   if (pp_opt(PP_OPT_MLP_SPLIT) & 16)            // split-precision chain kernel (pp_mlp_split.hip): bias sums included when asked for
-    return pp_launch_wgrad_chain_s(YA, XA, WA, YB, XB, WB, YC, XC, WC, kxc, count, rmul, rcap, st, bA, bB, bC);
+    return pp_launch_wgrad_chain_s(YA, XA, WA, YB, XB, WB, YC, XC, WC, kxc, count, rmul, rcap, st, bA, bB, bC, wgs);
   if (wgrad_split_enabled() && !bA) {
     // three launches of the self-scaling split-precision kernel (pp_gemm_split.h): three fp16 products per fp32 product,
     // error against fp64 equal to the fp32 matrix instructions'; load-bound instead of matrix-pipe bound
@@ -794,7 +794,8 @@ int pp_launch_wgrad_chain(const float* YA, const float* XA, float* WA, const flo
   }
   WgradLayer LA{YA, XA, WA, bA}, LB{YB, XB, WB, bB}, LC{YC, XC, WC, bC};
   const int npairs = pp_div_up(rcap, 2 * TILE_ROWS);
-  const int grid = npairs < PP_FUSED_WGS ? npairs : PP_FUSED_WGS;
+  const int cap_wgs = wgs > 0 ? (wgs < 16 ? 16 : wgs) : PP_FUSED_WGS;
+  const int grid = npairs < cap_wgs ? npairs : cap_wgs;
   if (kxc == 128)
     hipLaunchKernelGGL((k_wgrad_chain<128>), dim3(grid), dim3(256), 0, st, LA, LB, LC, count, rmul, rcap);
   else

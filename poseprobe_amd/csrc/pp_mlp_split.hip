@@ -1618,11 +1618,12 @@ __global__ __launch_bounds__(256) void k_wgrad_chain_s(WgradOperands LA, WgradOp
 
 int pp_launch_wgrad_chain_s(const float* YA, const float* XA, float* WA, const float* YB, const float* XB, float* WB,
                             const float* YC, const float* XC, float* WC, int kxc, const int32_t* count, int rmul, int rcap,
-                            hipStream_t st, float* bA, float* bB, float* bC) {
+                            hipStream_t st, float* bA, float* bB, float* bC, int wgs_) {
   WgradOperands LA{YA, XA, WA, bA}, LB{YB, XB, WB, bB}, LC{YC, XC, WC, bC};
   const int ntiles = pp_div_up(rcap, TILE_ROWS);
-  // persistent work-groups, at most one per CU over the three layers, shared out in proportion to the layers' work
-  const int wgs = PP_FUSED_WGS;
+  // persistent work-groups, at most one per CU over the three layers, shared out in proportion to the layers' work (wgs_ > 0: the
+  // caller's number - a launch on an auxiliary stream that leaves CUs to the kernels running beside it)
+  const int wgs = wgs_ > 0 ? (wgs_ < 16 ? 16 : wgs_) : PP_FUSED_WGS;
   // (a 64-wide layer costs 3/4 of a 128-wide one: three instead of four operand fragments to convert per 16-row group - the
   // conversion, not the MFMA count, is what the time follows)
   int nab = kxc == 128 ? wgs / 3 : (wgs * 4) / 11, nc = kxc == 128 ? wgs / 3 : wgs - 2 * ((wgs * 4) / 11);

@@ -211,7 +211,8 @@ class RenderCore:
         # Measured on MI355X (kernel trace): the overlap happens, but the small kernels only get the leftover wave slots
         # (15 -> 45 us each) and the fork / join edges cost ~10 us per chain, so the step is 1 % SLOWER - OFF by default,
         # PP_SIDE_STREAM=1 turns it on for experiments.
-        self.use_side_stream = use_side_stream or os.environ.get('PP_SIDE_STREAM') == '1'
+        self.use_side_stream = use_side_stream or os.environ.get('PP_SIDE_STREAM') in ('1', '2')
+        self.side_rgb_only = os.environ.get('PP_SIDE_STREAM') == '2'
 
     # -- forward -------------------------------------------------------------------------------------------
     def sample(self, ws, jitter):
@@ -265,7 +266,7 @@ class RenderCore:
                              ws.g_pts, ws.g_view_s, sdf_ab_grad)
         ops.context_join(ctx)           # rgbnet's weight-gradient kernel is done before the next register-hungry kernel
         ops.warp_bwd(warp_p, ws.pts, ws.warp_acts, ws.g_warp_out, ws.count, ws.cap, cfg.out_range, ws.scratch, warp_grad,
-                     ws.g_pts, ctx)
+                     ws.g_pts, None if getattr(self, 'side_rgb_only', False) else ctx)
         if not defer_join:
             ops.context_join(ctx)
         return ctx
