@@ -15,7 +15,10 @@
  *     launched for the capacity and retire surplus work-groups immediately;
  *   - fp32 values, int32 indices (the Python shim converts to int64 where the reference returns it);
  *   - return value: 0 on success, negative pp_status otherwise; pp_last_error() gives the text of
- *     the last failure on the calling thread.
+ *     the last failure on the calling thread;
+ *   - arguments are passed one by one rather than through per-op `pp_<op>_args` structs (SURVEY 8b sketched those): the binding
+ *     derives its prototypes from this header and so checks count and type of every argument; scratch sizes come from the
+ *     pp_*_workspace queries, tuning switches from pp_set_option - nothing else is process-wide.
  */
 #ifndef POSEPROBE_HIP_H
 #define POSEPROBE_HIP_H
