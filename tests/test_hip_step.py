@@ -352,3 +352,38 @@ def test_deterministic_scatter_makes_the_colour_grid_step_reproducible():
     assert float(grads[0].abs().max()) > 0
     assert torch.equal(grads[0], grads[1]) and torch.equal(grids[0], grids[1])
     assert_close(grads[2].cpu().numpy(), grads[0].cpu().numpy(), rtol=1e-5, atol=1e-9, scaled=1e-6, name='atomic vs sorted k0 gradient')
+
+
+@pytest.mark.parametrize('variant', ['mlp_wgs', 'side_stream'])
+def test_step_gradients_do_not_depend_on_work_group_counts_or_the_auxiliary_stream(variant):
+    """Options mlp_wgs / wgrad_side_wgs (fewer persistent work-groups) and the auxiliary-stream placement of the weight-gradient
+    kernels (RenderCore.use_side_stream) change the schedule, not the result: one step's gradients equal the default step's up to
+    the order of the float atomics."""
+    from poseprobe_amd import _lib, synthetic as syn
+    d = load('forward_g8_s10.npz')
+    V, H, W = d['images'].shape[:3]
+    idx, jit = syn.step_randomness(V * H * W, int(d['n_rand']), seed=91)
+    idx, jit = torch.tensor(idx, dtype=torch.int32, device='cuda'), torch.tensor(jit, device='cuda')
+
+    def grads(setup):
+        eng, _ = build_engine(d, pose_iters=1000)
+        setup(eng)
+        eng.zero_grads()
+        eng.render_and_grads(idx, jit, 10)
+        torch.cuda.synchronize()
+        return [t.detach().cpu().numpy().copy() for t in (eng.flat.grad, eng.se3_grad, eng.k0_grad)]
+
+    ref = grads(lambda eng: None)
+    old = {k: _lib.get_option(k) for k in ('mlp_wgs', 'wgrad_side_wgs')}
+    try:
+        if variant == 'mlp_wgs':
+            _lib.set_option('mlp_wgs', 48)
+            got = grads(lambda eng: None)
+        else:
+            _lib.set_option('wgrad_side_wgs', 96)
+            got = grads(lambda eng: setattr(eng.core, 'use_side_stream', True))
+    finally:
+        for k, v in old.items():
+            _lib.set_option(k, v)
+    for name, a, b in zip(('mlp / alpha / beta', 'se3', 'k0'), got, ref):
+        assert_close(a, b, rtol=1e-4, scaled=2e-6, name=f'{variant}: grad {name}')
