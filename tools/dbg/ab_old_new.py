@@ -33,6 +33,11 @@ for tag, kw in (('bench', {}), ('generic', dict(k0_dim=8, posbase_pe=3, viewbase
     ops.color_feat_fwd(cfg.pp, k0, pts, vd, rid, grad, pe_w, count, cap, feat)
     torch.cuda.synchronize()
     out[tag] = feat.cpu()
+    fg = torch.randn(cap, 64, generator=g).cuda()
+    pg, gg, vg = torch.zeros(cap, 3).cuda(), torch.zeros(cap, 3).cuda(), torch.zeros(cap, 3).cuda()
+    ops.color_feat_bwd(cfg.pp, k0, pts, vd, rid, grad, pe_w, count, cap, fg, None, pg, gg, vg)
+    torch.cuda.synchronize()
+    out[tag + '_bwd'] = torch.cat([pg[:M], gg[:M], vg[:M]], 1).cpu()
 if sys.argv[1] == 'save':
     torch.save(out, 'gpurun_out/ab_ref.pt')
     print('saved', list(out))
