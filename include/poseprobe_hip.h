@@ -340,6 +340,18 @@ int pp_sdf_first_crossing(const float* sdf, const int32_t* ray_start, const int3
                           const float* rays_d, float* sdf_dense, float* pts, uint8_t* mask, float* zval,
                           void* stream);
 
+/* Backward of the DENSE-mode query above when its SDF row is the border-padded trilinear lookup of the raw template at
+ * the dense sample positions p_k = o + d (t_min + dist (k + jitter) / |d|) (query_sdf_point_wocuda_wodeform,
+ * voxurf_coarse.py:797-837; the reference differentiates it by autograd and recon_scene.py:336-340 back-propagates the
+ * reprojection loss through it while at most two views are active).  sdf_grid [X,Y,Z]; sdf_dense[N,S] as returned by
+ * the forward; jitter[N] or NULL (eval).  Upstream: g_pts[N,3] and / or g_sdf_dense[N,S] (either may be NULL).
+ * Outputs (=): g_rays_o[N,3], g_rays_d[N,3] (incl. the |d| path), g_t_min[N]; t_min's own dependence on the ray
+ * (slab test, :701-705) is the caller's to chain. */
+int pp_sdf_crossing_dense_bwd(const pp_scene* sc, const float* sdf_grid, const float* rays_o, const float* rays_d,
+                              const float* t_min, const float* jitter, int32_t n_rays, int32_t n_samples, float dist,
+                              const float* sdf_dense, const float* g_pts, const float* g_sdf_dense, float* g_rays_o,
+                              float* g_rays_d, float* g_t_min, void* stream);
+
 /* ---------------------------------------------------------------- DVGO-surface operators of the reference's
  * extensions that the live loop never calls (SURVEY.md 2a "dead"), kept for API completeness:
  * raw2alpha{,_nonuni}{,_backward} (render_utils_kernel.cu:431-574; interval_v != NULL selects the per-point form),

@@ -375,6 +375,36 @@ def lookup_dense(scene, grid, xyz, padding_mode='zeros'):
     return out.squeeze(-1) if C == 1 else out
 
 
+def query_first_crossing(scene: Scene, sdf_d, t_min, rays_o, rays_d):
+    """Tail shared by query_sdf_point_wocuda / _wodeform (voxurf_coarse.py:766-786, :811-831): first sign change of the
+    dense SDF row, linear zero crossing, surface point -> pts [N,3], hit mask [N].  Differentiable like the reference."""
+    prev_sdf, next_sdf = sdf_d[:, :-1], sdf_d[:, 1:]
+    sign = prev_sdf * next_sdf
+    sign = torch.where(sign <= 0, torch.ones_like(sign), torch.zeros_like(sign))
+    prev_idx = torch.argmax(sign, 1, keepdim=True)
+    next_idx = prev_idx + 1
+    sdf1 = torch.gather(sdf_d, 1, prev_idx).squeeze(-1)
+    sdf2 = torch.gather(sdf_d, 1, next_idx).squeeze(-1)
+    dist = scene.stepsize * scene.voxel_size
+    z1 = prev_idx.squeeze(-1) * dist + dist * 0.5
+    z2 = next_idx.squeeze(-1) * dist + dist * 0.5
+    z0 = (sdf1 * z2 - sdf2 * z1) / (sdf1 - sdf2 + 1e-10)
+    z0 = torch.where(z0 < z1, torch.zeros_like(z0), z0)
+    z0 = torch.where(z0 > z2, torch.zeros_like(z0), z0)
+    hit = ((sdf1 * sdf2) < 0) * (z0 > 1e-10)
+    interpx = t_min + z0 / rays_d.norm(dim=-1, keepdim=False)
+    return rays_o + rays_d * interpx[..., None], hit
+
+
+def query_wodeform(scene: Scene, sdf_grid, rays_o, rays_d, jitter=None):
+    """query_sdf_point_wocuda_wodeform(keep_dim=True) (voxurf_coarse.py:797-833): RAW template looked up with border padding
+    (grid_sampler's F.grid_sample path, :539-540) at EVERY dense slot -> pts [N,3], hit [N], sdf_d [N,S]."""
+    pts, _, _, t_min, _ = sample_dense(scene, rays_o, rays_d, jitter)
+    sdf_d = lookup_dense(scene, sdf_grid, pts, padding_mode='border').reshape(pts.shape[0], pts.shape[1])
+    out, hit = query_first_crossing(scene, sdf_d, t_min, rays_o, rays_d)
+    return out, hit, sdf_d
+
+
 def mapped_sdf_grid(P):
     """sp10(alpha) * (sigmoid(sp10(beta) * sdf) - 0.5)   (voxurf_coarse.py:946-949)."""
     sp = lambda t: F.softplus(t, beta=10)

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_grid_sample_bwd(SceneDev sc, const floa
     if (border) {   // clipped coordinates have zero derivative outside the grid
       for (int a = 0; a < 3; ++a) {
         float u = pp_grid_u(p[a], sc.mn[a], sc.mx[a], sc.sz[a]);
-        if (u < 0.f || u > (float)(sc.sz[a] - 1)) pb[a] = 0.f;
+        if (u <= 0.f || u >= (float)(sc.sz[a] - 1)) pb[a] = 0.f;
       }
     }
   }
@@ -90,6 +90,114 @@ __global__ __launch_bounds__(256) void k_grid_sample_bwd(SceneDev sc, const floa
       v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
       if (live && ch == 0) pts_grad[m * 3 + a] = v * (float)(sc.sz[a] - 1) / (sc.mx[a] - sc.mn[a]);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of the dense surface-point query (Voxurf.query_sdf_point_wocuda_wodeform, lib/voxurf_coarse.py:797-837):
+//   p_k = o + d (t_min + dist (k + jitter) / |d|),  s_k = border-padded trilinear lookup of the RAW template at p_k,
+//   prev = first k with s_k s_{k+1} <= 0,  z0 = (s1 z2 - s2 z1) / (s1 - s2 + 1e-10)  (zeroed outside [z1, z2]),
+//   pts = o + d (t_min + z0 / |d|).
+// Given d L / d pts (and optionally d L / d s_k for the dense SDF row the query also returns) it produces d L / d o,
+// d L / d d and d L / d t_min (t_min's own dependence on the ray, the slab test of :701-705, is differentiated by the
+// caller).  One wavefront per ray; lanes walk the samples that carry a gradient (two of them unless g_sdf is given).
+// F.grid_sample's 'border' rule: a clipped coordinate (u <= 0 or u >= size-1) has zero derivative.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void border_tri_grad(const SceneDev& sc, const float* __restrict__ grid, const float p[3],
+                                                float g[3]) {
+  float w0[3], w1[3], mult[3];
+  int i0[3], i1[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float u = pp_grid_u(p[a], sc.mn[a], sc.mx[a], sc.sz[a]);
+    float top = (float)(sc.sz[a] - 1);
+    mult[a] = (u <= 0.f || u >= top) ? 0.f : top / (sc.mx[a] - sc.mn[a]);
+    u = fminf(fmaxf(u, 0.f), top);
+    float f = floorf(u);
+    w1[a] = u - f;
+    w0[a] = 1.f - w1[a];
+    i0[a] = min(max((int)f, 0), sc.sz[a] - 1);
+    i1[a] = min(i0[a] + 1, sc.sz[a] - 1);
+  }
+  g[0] = g[1] = g[2] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    int ix = (c & 4) ? i1[0] : i0[0], iy = (c & 2) ? i1[1] : i0[1], iz = (c & 1) ? i1[2] : i0[2];
+    float wx = (c & 4) ? w1[0] : w0[0], wy = (c & 2) ? w1[1] : w0[1], wz = (c & 1) ? w1[2] : w0[2];
+    float v = grid[((size_t)ix * sc.sz[1] + iy) * sc.sz[2] + iz];
+    g[0] += ((c & 4) ? v : -v) * wy * wz;
+    g[1] += ((c & 2) ? v : -v) * wx * wz;
+    g[2] += ((c & 1) ? v : -v) * wx * wy;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) g[a] *= mult[a];
+}
+
+__global__ __launch_bounds__(256) void k_crossing_dense_bwd(SceneDev sc, const float* __restrict__ grid,
+                                                            const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                            const float* __restrict__ t_min, const float* __restrict__ jitter,
+                                                            int n_rays, int S, float dist, const float* __restrict__ sdf_dense,
+                                                            const float* __restrict__ g_pts, const float* __restrict__ g_sdf,
+                                                            float* __restrict__ g_o, float* __restrict__ g_d,
+                                                            float* __restrict__ g_tmin) {
+  int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int r = blockIdx.x * 4 + wid;
+  if (r >= n_rays) return;
+  const float* row = sdf_dense + (size_t)r * S;
+  int prev = 0;
+  for (int k0 = 0; k0 < S - 1; k0 += 64) {
+    int k = k0 + lane;
+    bool hit = (k < S - 1) && (row[k] * row[k + 1] <= 0.f);
+    unsigned long long bal = __ballot(hit);
+    if (bal) { prev = k0 + __ffsll((long long)bal) - 1; break; }
+  }
+  float o[3] = {rays_o[r * 3], rays_o[r * 3 + 1], rays_o[r * 3 + 2]};
+  float d[3] = {rays_d[r * 3], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
+  float nrm = sqrtf(fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0])));
+  float tm = t_min[r], jit = jitter ? jitter[r] : 0.f;
+  float s1 = row[prev], s2 = row[prev + 1];
+  float z1 = (float)prev * dist + dist * 0.5f, z2 = (float)(prev + 1) * dist + dist * 0.5f;
+  float den = s1 - s2 + 1e-10f;
+  float z0 = (s1 * z2 - s2 * z1) / den;
+  bool kept = !(z0 < z1) && !(z0 > z2);               // the two torch.where's replace z0 by a constant 0 otherwise
+  float z0c = kept ? z0 : 0.f;
+  float G[3] = {0.f, 0.f, 0.f};
+  if (g_pts) { G[0] = g_pts[r * 3]; G[1] = g_pts[r * 3 + 1]; G[2] = g_pts[r * 3 + 2]; }
+  float gi = G[0] * d[0] + G[1] * d[1] + G[2] * d[2];
+  float g_z0 = kept ? gi / nrm : 0.f;
+  float g_s1 = g_z0 * (z2 - z0) / den, g_s2 = g_z0 * (z0 - z1) / den;
+  float ao[3] = {0.f, 0.f, 0.f}, ad[3] = {0.f, 0.f, 0.f}, atm = 0.f, an = 0.f;
+  if (lane == 0) {
+    float interp = tm + z0c / nrm;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { ao[a] = G[a]; ad[a] = G[a] * interp; }
+    atm = gi;
+    an = -gi * z0c / (nrm * nrm);
+  }
+  for (int k = lane; k < S; k += 64) {
+    float gs = g_sdf ? g_sdf[(size_t)r * S + k] : 0.f;
+    if (k == prev) gs += g_s1;
+    if (k == prev + 1) gs += g_s2;
+    if (gs == 0.f) continue;
+    float st = dist * ((float)k + jit);
+    float interp = tm + st / nrm;
+    float p[3] = {o[0] + d[0] * interp, o[1] + d[1] * interp, o[2] + d[2] * interp};
+    float gp[3];
+    border_tri_grad(sc, grid, p, gp);
+    float gid = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { gp[a] *= gs; ao[a] += gp[a]; ad[a] += gp[a] * interp; gid += gp[a] * d[a]; }
+    atm += gid;
+    an -= gid * st / (nrm * nrm);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { ao[a] = pp_wave_sum(ao[a]); ad[a] = pp_wave_sum(ad[a]); }
+  atm = pp_wave_sum(atm);
+  an = pp_wave_sum(an);
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { g_o[r * 3 + a] = ao[a]; g_d[r * 3 + a] = ad[a] + an * d[a] / nrm; }
+    g_tmin[r] = atm;
   }
 }
 
@@ -147,6 +255,20 @@ extern "C" int pp_grid_tv_grad(const float* p, int32_t size_x, int32_t size_y, i
   PP_REQUIRE(p && grad, "null pointer");
   hipLaunchKernelGGL(k_grid_tv_grad, dim3(2048), dim3(256), 0, pp_stream(stream), p, size_x, size_y, size_z, channels,
                      scale, g_scalar, grad);
+  PP_CHECK_LAUNCH();
+  return PP_OK;
+}
+
+extern "C" int pp_sdf_crossing_dense_bwd(const pp_scene* sc, const float* sdf_grid, const float* rays_o, const float* rays_d,
+                                         const float* t_min, const float* jitter, int32_t n_rays, int32_t n_samples,
+                                         float dist, const float* sdf_dense, const float* g_pts, const float* g_sdf_dense,
+                                         float* g_rays_o, float* g_rays_d, float* g_t_min, void* stream) {
+  PP_REQUIRE(sc && sdf_grid && rays_o && rays_d && t_min && sdf_dense && g_rays_o && g_rays_d && g_t_min, "null pointer");
+  PP_REQUIRE(g_pts || g_sdf_dense, "need at least one upstream gradient");
+  PP_REQUIRE(n_rays > 0 && n_samples >= 2, "need n_rays>0 and n_samples>=2");
+  hipLaunchKernelGGL(k_crossing_dense_bwd, dim3(pp_div_up(n_rays, 4)), dim3(256), 0, pp_stream(stream), pp_scene_dev(sc),
+                     sdf_grid, rays_o, rays_d, t_min, jitter, n_rays, n_samples, dist, sdf_dense, g_pts, g_sdf_dense, g_rays_o,
+                     g_rays_d, g_t_min);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }

@@ -514,6 +514,29 @@ class TrainEngine:
             sd[f'warp_network.deform_net.net.net.{i}.0.bias'] = c(b)
         return sd
 
+    def voxurf_view(self, model=None):
+        """The drop-in `Voxurf` module over this engine's CURRENT parameters, for the callers either side of the train step
+        that want the module API (surface queries, reprojection losses, inference): built once from `model_kwargs()`; every
+        call re-points `k0.grid` at the live ping-pong buffer (zero-copy, channels-last) and the SDF template at the engine's,
+        and copies the small parameters (alpha / beta, both MLPs: 370 KB) on the device.  Nothing goes through the host."""
+        from . import voxurf_coarse
+        if model is None:
+            model = voxurf_coarse.Voxurf(**self.model_kwargs()).to(self.dev)
+        P = self.flat
+        with torch.no_grad():
+            model.k0.grid.data = self.k0_reference_layout()
+            model.sdf.grid.data = self.sdf[None, None]
+            model.sdf_alpha.data.copy_(P.view('sdf_ab')[0:1])
+            model.sdf_beta.data.copy_(P.view('sdf_ab')[1:2])
+            sd = dict(model.named_parameters())
+            for key, (W, b) in zip(self.RGBNET_KEYS, unpack_rgbnet(P.view('rgbnet'))):
+                sd[key + '.weight'].data.copy_(W)
+                sd[key + '.bias'].data.copy_(b)
+            for i, (W, b) in enumerate(unpack_warp(P.view('warp'))):
+                sd[f'warp_network.deform_net.net.net.{i}.0.weight'].data.copy_(W)
+                sd[f'warp_network.deform_net.net.net.{i}.0.bias'].data.copy_(b)
+        return model
+
     def load_model_state_dict(self, sd):
         rg = [(sd[k + '.weight'], sd[k + '.bias']) for k in self.RGBNET_KEYS]
         wp = [(sd[f'warp_network.deform_net.net.net.{i}.0.weight'], sd[f'warp_network.deform_net.net.net.{i}.0.bias'])

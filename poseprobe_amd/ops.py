@@ -326,6 +326,13 @@ def sdf_first_crossing(sdf, ray_start, step_k, n_rays, n_samples, dist, t_min, r
               _f(rays_o), _f(rays_d), _f(sdf_dense), _f(pts), _ptr(mask, torch.uint8), _f(zval), _stream())
 
 
+def sdf_crossing_dense_bwd(sc, sdf_grid, rays_o, rays_d, t_min, jitter, n_rays, n_samples, dist, sdf_dense, g_pts, g_sdf_dense,
+                           g_rays_o, g_rays_d, g_t_min):
+    _lib.call('pp_sdf_crossing_dense_bwd', ctypes.byref(sc), _f(sdf_grid), _f(rays_o), _f(rays_d), _f(t_min), _f(jitter),
+              n_rays, n_samples, float(dist), _f(sdf_dense), _f(g_pts), _f(g_sdf_dense), _f(g_rays_o), _f(g_rays_d),
+              _f(g_t_min), _stream())
+
+
 def feat_generic_fwd(sc, k0_cl, pts, viewdirs, ray_id, gradient, pe_w, sel, k0_skip, ld, count, capacity, feat, k0_raw):
     _lib.call('pp_feat_generic_fwd', ctypes.byref(sc), _f(k0_cl), _f(pts), _f(viewdirs), _i(ray_id), _f(gradient), _f(pe_w),
               _ptr(sel, torch.uint8), int(k0_skip), int(ld), _i(count), capacity, _f(feat), _f(k0_raw), _stream())

@@ -116,4 +116,5 @@ def get_project_error(model, Ks, HW, nl, global_step, current_pose, coord0, coor
     valid = (~behind[..., 0]) & hit.bool()
     if pixel_thre is not None:
         valid = valid & (dist.detach() <= pixel_thre)
+    get_project_error.last_valid = valid            # diagnostics for callers / tests (how many matches took part)
     return compute_diff_loss('huber', dist, weights=conf, mask=valid, delta=1.), near_surface

@@ -13,6 +13,7 @@ Schedules (all pure functions of the step, unit-tested on the CPU):
 """
 import os
 
+import numpy as np
 import torch
 
 from . import bg_nerf
@@ -49,6 +50,53 @@ def active_views(global_step, n_views, incremental_step, incremental=True, start
 def object_phase(global_step, n_iters_object, start_object=0):
     """The object branch is optimised while start_object <= step <= cfg_train.N_iters (lib/recon_scene.py:584)."""
     return start_object <= global_step <= n_iters_object
+
+
+class ReprojectionTerm:
+    """The reprojection + near-surface pose terms of the live loop (lib/recon_scene.py:624-637) as a `pose_terms` entry of
+    DualBranchTrainer: one matched view pair is drawn per step among the ACTIVE views, every matched pixel is lifted to the
+    current surface, moved into the other view and compared with its match (recon_utils.get_project_error).  The surface
+    point comes from the zero-crossing query of the raw template while at most two views are active
+    (`pose_use_deform = optimize_object_nerf and len(selected_i_train) > 2`, :584 - i.e. at the start of EVERY run) and from
+    the rendered depth afterwards; both are differentiated by the HIP backward (pp_sdf_crossing_dense_bwd / the render
+    chain), so the pose receives the reference's gradient in either phase.
+
+    pairs: list of (i, j, coord_i [P,2], coord_j [P,2], conf [P]) - matcher output, an input here as in bg_losses.
+    weight_projection / weight_near_surface: cfg_train.projection_dis_error / cfg_train.weight_near_surface
+    (configs/dtu_e2e/scan1.py:60-61: 1e-3 / 1e-1)."""
+    __name__ = 'reprojection'
+
+    def __init__(self, obj_engine, pairs, nl, weight_projection, weight_near_surface, pixel_thre=200, inverse_y=True,
+                 flip_x=False, flip_y=False, seed=0):
+        self.e, self.pairs = obj_engine, list(pairs)
+        self.nl, self.w_proj, self.w_near, self.pixel_thre = float(nl), float(weight_projection), float(weight_near_surface), pixel_thre
+        self.flags = dict(inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y)
+        self.rng = np.random.RandomState(seed)
+        self.model = obj_engine.voxurf_view()
+        self.global_step = 0
+        self.last = {}
+
+    def __call__(self, se3, w2c_init, n_active):
+        from . import camera, recon_utils
+        e = self.e
+        live = [p for p in self.pairs if p[0] < n_active and p[1] < n_active]
+        if not live:
+            return 0.0, se3.sum() * 0.0
+        i, j, ci, cj, conf = live[self.rng.randint(len(live))]
+        use_deform = n_active > 2                                   # recon_scene.py:584
+        if use_deform:
+            e.voxurf_view(self.model)                               # the rendered-depth query reads the current parameters
+        w2c, _ = camera.current_pose_c2w(se3, w2c_init, fix_first=bool(e.refine_mask[0] == 0))
+        cfg = e.cfg
+        Ks = torch.zeros(e.V, 3, 3, device=e.dev)
+        Ks[:, 0, 0], Ks[:, 1, 1], Ks[:, 0, 2], Ks[:, 1, 2], Ks[:, 2, 2] = e.intr[:, 0], e.intr[:, 1], e.intr[:, 2], e.intr[:, 3], 1.
+        err, near = recon_utils.get_project_error(
+            self.model, Ks, np.array([[e.H, e.W]] * e.V), self.nl, self.global_step, w2c, cj[None].to(e.dev), ci[None].to(e.dev),
+            np.array([j]), np.array([i]), conf[None].to(e.dev), use_deform=use_deform, pixel_thre=self.pixel_thre,
+            near=cfg.near, far=cfg.far, bg=cfg.bg, stepsize=cfg.stepsize, **self.flags)
+        self.last = dict(projection_dis_error=float(err.detach()), loss_near_surface=float(near.detach()), use_deform=use_deform,
+                         pair=(i, j), hits=int(recon_utils.get_project_error.last_valid.sum()))
+        return 1.0, self.w_near * near + self.w_proj * err
 
 
 class DualBranchTrainer:
@@ -117,6 +165,8 @@ class DualBranchTrainer:
         se3 = e.se3.detach().clone().requires_grad_(True)
         values, total = {}, 0.
         for i, term in enumerate(self.pose_terms):
+            if hasattr(term, 'global_step'):
+                term.global_step = self.global_step
             w, val = term(se3, e.w2c_init, k)
             values[getattr(term, '__name__', f'term{i}')] = float(val.detach())
             total = total + w * val
@@ -127,6 +177,7 @@ class DualBranchTrainer:
     def train_step(self, global_step):
         """One iteration of the joint loop; returns (object-branch summary, scene loss)."""
         self.iteration += 1
+        self.global_step = global_step
         k = self._admit_views(global_step)
         fine = fine_phase(global_step, self.max_iter, self.ratio_start_fine, self.nerf_fine is not None)
         ray_idx, jitter, pixels, image = self.sample_batch(k)

@@ -225,6 +225,46 @@ class _WarpNet(nn.Module):
         return [seq[0] for seq in self.deform_net.net.net]
 
 
+class _CrossingDense(torch.autograd.Function):
+    """query_sdf_point_wocuda_wodeform (lib/voxurf_coarse.py:797-837) as one differentiable node: RAW template looked up with
+    border padding at every dense slot, first sign change, linear zero crossing.  Inputs that carry gradients: rays_o, rays_d
+    and t_min (the torch restatement of the slab test, so that d t_min / d ray is chained by autograd); outputs pts [N,3]
+    and the dense SDF row [N,S] are differentiable, the hit mask is not."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, t_min_graph, model, core, grid, jitter, dist, render_kwargs):
+        cfg = core.cfg
+        ro, rd = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
+        N, S, dev = ro.shape[0], cfg.n_samples, ro.device
+        pts_all, _, _, t_min, _ = model.sample_ray_ori(ro, rd, render_kwargs['near'], render_kwargs['far'],
+                                                       render_kwargs['stepsize'], is_train=jitter is not None, jitter=jitter)
+        dense = torch.empty(N * S, 1, device=dev)
+        ops.grid_sample_fwd(cfg.pp, grid, 1, pts_all.reshape(-1, 3).contiguous(), 1, dense)
+        dense = dense.reshape(N, S)
+        pts_out = torch.empty(N, 3, device=dev)
+        mask = torch.empty(N, device=dev, dtype=torch.uint8)
+        sdf_d = torch.empty(N, S, device=dev)
+        ops.sdf_first_crossing(dense, None, None, N, S, dist, t_min, ro, rd, sdf_d, pts_out, mask, None)
+        mask = mask.bool()
+        if ctx is not None:
+            ctx.save_for_backward(ro, rd, t_min, sdf_d, grid, jitter)
+            ctx.pp, ctx.dist = cfg.pp, dist
+            ctx.mark_non_differentiable(mask)
+        return pts_out, mask, sdf_d
+
+    @staticmethod
+    def backward(ctx, g_pts, _g_mask, g_sdf):
+        ro, rd, t_min, sdf_d, grid, jitter = ctx.saved_tensors
+        N, S = sdf_d.shape
+        g_o, g_d, g_t = torch.empty_like(ro), torch.empty_like(rd), torch.empty_like(t_min)
+        if g_pts is None and g_sdf is None:
+            return (None,) * 9
+        ops.sdf_crossing_dense_bwd(ctx.pp, grid, ro, rd, t_min, jitter, N, S, ctx.dist, sdf_d,
+                                   None if g_pts is None else g_pts.contiguous().float(),
+                                   None if g_sdf is None else g_sdf.contiguous().float(), g_o, g_d, g_t)
+        return g_o, g_d, g_t, None, None, None, None, None, None
+
+
 class Voxurf(torch.nn.Module):
     """lib/voxurf_coarse.py:45-1263 (constructor :49-229)."""
 
@@ -418,23 +458,39 @@ class Voxurf(torch.nn.Module):
 
 
     # ---- surface-point queries (voxurf_coarse.py:734-920) -------------------------------------------------------
-    @torch.no_grad()
     def _query_crossing(self, rays_o, rays_d, global_step, use_deform, mapped, render_kwargs):
+        """mapped=True: query_sdf_point_wocuda (mapped SDF at the in-bbox samples, optional warp), forward only - its one caller,
+        the PnP hand-off (recon_scene.py:290-296), detaches the points.  mapped=False: query_sdf_point_wocuda_wodeform, which
+        the live loop differentiates w.r.t. the rays (recon_scene.py:336-340 while <= 2 views are active): an autograd node
+        whose backward is pp_sdf_crossing_dense_bwd."""
         self._check_inputs(rays_o, rays_d)
         core = self._scene(dict(bg=0, **{k: render_kwargs[k] for k in ('near', 'far', 'stepsize')}))
         cfg = core.cfg
-        ro, rd = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
-        N, S, dev = ro.shape[0], cfg.n_samples, ro.device
+        N, S, dev = rays_o.shape[0], cfg.n_samples, rays_o.device
         is_train = global_step is not None
         jitter = None
         if is_train:
             jitter = render_kwargs.get('jitter')
             jitter = torch.rand(N, device=dev) if jitter is None else jitter.to(dev).float().contiguous()
         dist = float(np.float32(cfg.stepsize) * np.float32(cfg.voxel_size))
-        pts_out = torch.empty(N, 3, device=dev)
-        mask = torch.empty(N, device=dev, dtype=torch.uint8)
-        sdf_d = torch.empty(N, S, device=dev)
-        if mapped:
+        if not mapped:
+            needs_grad = torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad)
+            # t_min enters the surface point explicitly; its dependence on the ray (slab test) is plain torch algebra
+            t_min = self._entry_distance(rays_o, rays_d, render_kwargs['near'], render_kwargs['far']) if needs_grad else None
+            grid = self.sdf.grid[0, 0].contiguous()
+            if needs_grad:
+                pts, mask, sdf_d = _CrossingDense.apply(rays_o, rays_d, t_min, self, core, grid, jitter, dist,
+                                                        render_kwargs)
+            else:
+                with torch.no_grad():
+                    pts, mask, sdf_d = _CrossingDense.forward(None, rays_o, rays_d, None, self, core, grid, jitter, dist,
+                                                              render_kwargs)
+            return pts, mask, sdf_d
+        with torch.no_grad():
+            ro, rd = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
+            pts_out = torch.empty(N, 3, device=dev)
+            mask = torch.empty(N, device=dev, dtype=torch.uint8)
+            sdf_d = torch.empty(N, S, device=dev)
             sb = self._sample_dense(core, ro, rd, jitter)
             M = sb['M']
             cap = max(M, 1)
@@ -453,14 +509,6 @@ class Voxurf(torch.nn.Module):
                                  vd.contiguous(), sb['ray_id'], sb['count'], cap, 1.0, alpha, grad, sdf_final, None, None)
             ops.sdf_first_crossing(sdf_final, sb['ray_start'], sb['step_k'], N, S, dist, sb['t_min'], ro, rd, sdf_d,
                                    pts_out, mask, None)
-        else:
-            # _wodeform: RAW template, every dense slot looked up with border padding (voxurf_coarse.py:805-809)
-            pts_all, _, _, t_min, _ = self.sample_ray_ori(ro, rd, render_kwargs['near'], render_kwargs['far'],
-                                                          render_kwargs['stepsize'], is_train=is_train, jitter=jitter)
-            dense = torch.empty(N * S, 1, device=dev)
-            ops.grid_sample_fwd(cfg.pp, self.sdf.grid[0, 0].contiguous(), 1, pts_all.reshape(-1, 3).contiguous(), 1, dense)
-            ops.sdf_first_crossing(dense.reshape(N, S).contiguous(), None, None, N, S, dist, t_min, ro, rd, sdf_d, pts_out,
-                                   mask, None)
         return pts_out, mask.bool(), sdf_d
 
     def _query_finish(self, rays_o, rays_d, pts, mask, sdf_d, keep_dim, return_depth, t_min_fn=None):
@@ -474,13 +522,13 @@ class Voxurf(torch.nn.Module):
 
     def query_sdf_point_wocuda(self, rays_o, rays_d, global_step=None, keep_dim=False, return_depth=False,
                                use_deform=False, **render_kwargs):
-        """voxurf_coarse.py:734-795 (forward only: the HIP path does not differentiate through the zero crossing)."""
+        """voxurf_coarse.py:734-795 (forward only here: the reference's one caller detaches the points, recon_scene.py:290-296)."""
         pts, mask, sdf_d = self._query_crossing(rays_o, rays_d, global_step, use_deform, True, render_kwargs)
         return self._query_finish(rays_o, rays_d, pts, mask, sdf_d, keep_dim, return_depth)
 
     def query_sdf_point_wocuda_wodeform(self, rays_o, rays_d, global_step=None, keep_dim=False, return_depth=False,
                                         **render_kwargs):
-        """voxurf_coarse.py:797-837"""
+        """voxurf_coarse.py:797-837; differentiable w.r.t. rays_o / rays_d (pose gradient of the reprojection loss)."""
         pts, mask, sdf_d = self._query_crossing(rays_o, rays_d, global_step, False, False, render_kwargs)
         return self._query_finish(rays_o, rays_d, pts, mask, sdf_d, keep_dim, return_depth)
 

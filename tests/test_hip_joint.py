@@ -222,3 +222,73 @@ def test_trainer_incremental_views_pose_hand_off_and_loss_mixing():
         expect = 0.1 * 0.5 * 2.0 * eng.se3 * eng.refine_mask[:, None]
         assert_close(eng.se3_grad, expect.cpu(), rtol=1e-6, atol=1e-9, name='mixed pose term')
         eng.se3_grad.zero_()
+
+
+def test_reprojection_term_differentiates_the_zero_crossing_query_while_two_views_are_active():
+    """trainer.ReprojectionTerm (lib/recon_scene.py:584, :624-637): with <= 2 active views the surface point is the zero
+    crossing of the raw template and its pose gradient flows through pp_sdf_crossing_dense_bwd (BOTH views of the pair
+    receive a gradient: the 'own' view through the query's rays, the other through world2cam); with 3 views it is the
+    rendered depth.  The mixed gradient equals the term's autograd gradient times loss_scale on the refined views."""
+    from poseprobe_amd import bg_nerf, camera, recon_utils
+    from poseprobe_amd.trainer import DualBranchTrainer, ReprojectionTerm
+    d = load('forward_g24_s10.npz')
+    eng, _ = build_engine(d)
+    eng.zero_grads()
+    H, W = eng.H, eng.W
+    g = torch.Generator().manual_seed(11)
+    P = 40
+    mk = lambda: (torch.rand(P, 2, generator=g) * torch.tensor([W - 1., H - 1.]) * 0.5 + torch.tensor([W, H]) * 0.25)
+    pairs = [(0, 1, mk(), mk(), torch.rand(P, generator=g)), (1, 2, mk(), mk(), torch.rand(P, generator=g)),
+             (0, 2, mk(), mk(), torch.rand(P, generator=g))]
+    term = ReprojectionTerm(eng, pairs, nl=0.1, weight_projection=1.0, weight_near_surface=0.1, seed=0)
+    with torch.no_grad():
+        eng.refine_mask[0] = 1                  # let view 0 move too, so that BOTH views of the (0, 1) pair show their share
+    se3 = eng.se3.detach().clone().requires_grad_(True)
+    torch.manual_seed(7)                        # the query draws its per-ray jitter from the global generator (as the reference does)
+    w, val = term(se3, eng.w2c_init, 2)
+    assert term.last['use_deform'] is False and term.last['pair'] == (0, 1) and w == 1.0
+    val.backward()
+    g2 = se3.grad.clone()
+    assert float(g2[0].abs().max()) > 0 and float(g2[1].abs().max()) > 0 and float(g2[2].abs().max()) == 0
+    # the same loss with the surface points detached: only the world2cam half of the gradient is left (what round 2 had)
+    i, j, ci, cj, conf = pairs[0]
+
+    class Detached:
+        xyz_min, xyz_max, diagonal_length = term.model.xyz_min, term.model.xyz_max, term.model.diagonal_length
+
+        def query_sdf_point_wocuda_wodeform(self, o, dd, **kw):
+            p, m, s = term.model.query_sdf_point_wocuda_wodeform(o.detach(), dd.detach(), **kw)
+            return p.detach(), m, s
+
+    se3b = eng.se3.detach().clone().requires_grad_(True)
+    w2c, _ = camera.current_pose_c2w(se3b, eng.w2c_init, fix_first=False)
+    Ks = torch.zeros(3, 3, 3, device='cuda')
+    Ks[:, 0, 0], Ks[:, 1, 1], Ks[:, 0, 2], Ks[:, 1, 2], Ks[:, 2, 2] = eng.intr[:, 0], eng.intr[:, 1], eng.intr[:, 2], eng.intr[:, 3], 1.
+    torch.manual_seed(7)
+    err, near = recon_utils.get_project_error(Detached(), Ks, np.array([[H, W]] * 3), 0.1, 0, w2c, cj[None].cuda(), ci[None].cuda(),
+                                              np.array([j]), np.array([i]), conf[None].cuda(), use_deform=False, pixel_thre=200,
+                                              near=eng.cfg.near, far=eng.cfg.far, bg=0, stepsize=eng.cfg.stepsize)
+    assert_close(np.float32((0.1 * near + 1.0 * err).item()), np.float32(val.item()), rtol=1e-5, atol=1e-7, name='term value')
+    (0.1 * near + 1.0 * err).backward()
+    assert int(term.last['hits']) >= 10, term.last
+    assert float((g2 - se3b.grad).abs().max()) > 0.02 * float(g2.abs().max()), 'the query must contribute to the pose gradient'
+    # three active views: rendered-depth query over the engine's live parameters
+    se3c = eng.se3.detach().clone().requires_grad_(True)
+    term.rng = np.random.RandomState(1)
+    w, val3 = term(se3c, eng.w2c_init, 3)
+    assert term.last['use_deform'] is True
+    val3.backward()
+    assert torch.isfinite(se3c.grad).all() and float(se3c.grad.abs().max()) > 0
+    # mixing into the engine's pose gradient through the trainer
+    opt = bg_nerf.default_options(sample_intvs=16)
+    opt.nerf.rand_rays = 96
+    term.rng = np.random.RandomState(0)
+    tr = DualBranchTrainer(eng, opt, max_iter=20, incremental_step=4, pose_terms=(term,))
+    tr.global_step = 0
+    eng.se3_grad.zero_()
+    torch.manual_seed(7)
+    vals = tr._mix_pose_terms(2)
+    assert 'reprojection' in vals
+    assert_close(eng.se3_grad, (eng.loss_scale * g2 * eng.refine_mask[:, None]).cpu(), rtol=1e-4, atol=1e-7, name='mixed reprojection gradient')
+    tr.train_step(0)                                            # and a whole joint step runs with it
+    assert term.last['use_deform'] is False

@@ -30,6 +30,44 @@ def test_ray_helpers_match_reference_cpu():
     assert abs(float(got) - (0.125 + 2 * 2.5) / (2 + 1e-6)) < 1e-6
 
 
+class _OracleSurface:
+    """The oracle's zero-crossing query behind the three attributes / one method get_project_error needs (CPU checker)."""
+
+    def __init__(self, d):
+        from oracle import voxurf_oracle as O
+        from poseprobe_amd import synthetic as syn
+        G = int(d['G'])
+        rs = syn.range_shape()
+        self.O = O
+        self.scene = O.Scene(syn.XYZ_MIN, syn.XYZ_MAX, G ** 3, output_range=float(rs.max()), rect_size=rs.tolist())
+        self.sdf = torch.tensor(d['P.sdf'])
+        self.xyz_min, self.xyz_max = self.scene.xyz_min, self.scene.xyz_max
+        self.diagonal_length = torch.sqrt(torch.sum(self.xyz_max - self.xyz_min ** 2))       # sic, lib/voxurf_coarse.py:102
+
+    def query_sdf_point_wocuda_wodeform(self, o, dd, global_step=None, keep_dim=True, jitter=None, **_):
+        return self.O.query_wodeform(self.scene, self.sdf, o, dd, jitter if global_step is not None else None)
+
+
+def test_oracle_zero_crossing_query_reproduces_the_reference_pose_gradient_cpu():
+    """oracle.query_wodeform (restating lib/voxurf_coarse.py:797-837) inside recon_utils.get_project_error against what the
+    reference's own get_project_error(use_deform=False) produced: both losses and d/d se3 (fixture g_se3_plain)."""
+    from oracle import voxurf_oracle as O
+    from poseprobe_amd import recon_utils as R
+    d = load('reproj_g24.npz')
+    se3 = torch.tensor(d['se3'], requires_grad=True)
+    init = torch.tensor(d['w2c_init'])
+    w2c = torch.cat([init[:1], O.pose_compose_pair(O.se3_to_SE3(se3), init)[1:]], 0)    # the package's lie algebra is HIP-only
+    err, near = R.get_project_error(_OracleSurface(d), torch.tensor(d['Ks']), np.array([[int(d['H']), int(d['W'])]] * 3),
+                                    float(d['nl']), 50, w2c, torch.tensor(d['coord0']), torch.tensor(d['coord1']), d['i_train'],
+                                    d['j_train'], torch.tensor(d['mconf']), use_deform=False, pixel_thre=200, near=0.24, far=4.8,
+                                    bg=0, stepsize=1.5, flip_x=False, flip_y=False, jitter=torch.tensor(d['jitter']))
+    assert_close(np.float32(err.item()), d['err_plain'], rtol=2e-4, atol=1e-5, name='projection_dis_error')
+    assert_close(np.float32(near.item()), d['near_plain'], rtol=1e-5, atol=1e-5, name='near_surface_loss')
+    (err + near).backward()
+    assert np.abs(d['g_se3_plain']).max() > 1.0                  # the fixture's gradient is far from zero
+    assert_close(se3.grad.numpy(), d['g_se3_plain'], rtol=1e-3, atol=1e-4, scaled=1e-4, name='d/d se3 (zero-crossing query)')
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('use_deform', [True, False])
 def test_project_error_matches_reference(use_deform):
@@ -51,9 +89,55 @@ def test_project_error_matches_reference(use_deform):
     tag = 'deform' if use_deform else 'plain'
     assert_close(np.float32(err.item()), d[f'err_{tag}'], rtol=2e-4, atol=1e-5, name='projection_dis_error')
     assert_close(np.float32(near.item()), d[f'near_{tag}'], rtol=1e-5, atol=1e-5, name='near_surface_loss')
-    if use_deform:          # the rendered-depth query is differentiable end to end (pose gradient through the HIP backward)
-        (err + near).backward()
-        assert_close(se3.grad.cpu().numpy(), d['g_se3_deform'], rtol=2e-3, atol=1e-4, scaled=1e-3, name='d/d se3')
+    # both queries are differentiable end to end: the rendered-depth query through the render backward, the zero-crossing query
+    # (use_deform=False: what the live loop runs while <= 2 views are active, recon_scene.py:584, :624-631) through
+    # pp_sdf_crossing_dense_bwd
+    (err + near).backward()
+    assert_close(se3.grad.cpu().numpy(), d[f'g_se3_{tag}'], rtol=2e-3, atol=1e-4, scaled=1e-3, name='d/d se3')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('train', [True, False])
+def test_zero_crossing_query_backward_matches_the_oracle(train):
+    """A random linear functional over BOTH differentiable outputs of query_sdf_point_wocuda_wodeform (surface points and
+    the dense SDF row) differentiated w.r.t. rays_o / rays_d by the HIP node and by the oracle (autograd over its restatement
+    of lib/voxurf_coarse.py:797-837), incl. rays that miss the box, rays without a crossing and un-normalised directions."""
+    from oracle import voxurf_oracle as O
+    from tests.test_hip_dropin import make_model
+    d = load('reproj_g24.npz')
+    m = make_model(d)
+    surf = _OracleSurface(d)
+    g = torch.Generator().manual_seed(5)
+    N = 301
+    o = torch.randn(N, 3, generator=g) * 0.15 + torch.tensor([0.0, 0.0, -1.6])
+    tgt = (torch.rand(N, 3, generator=g) - 0.5) * torch.tensor([1.6, 1.6, 1.4]) + torch.tensor([0., 0., -0.1])
+    dd = tgt - o
+    dd = dd / dd.norm(dim=-1, keepdim=True) * (0.5 + torch.rand(N, 1, generator=g))       # |d| != 1: the norm path counts
+    jit = torch.rand(N, generator=g) if train else None
+    c_pts, c_sdf = torch.randn(N, 3, generator=g), torch.randn(N, surf.scene.n_samples(), generator=g) * 0.05
+    rk = dict(near=0.24, far=4.8, stepsize=1.5, bg=0)
+    res = {}
+    for name, dev in (('oracle', 'cpu'), ('hip', 'cuda')):
+        oo, dv = o.clone().to(dev).requires_grad_(True), dd.clone().to(dev).requires_grad_(True)
+        if name == 'oracle':
+            pts, hit, sdf_d = O.query_wodeform(surf.scene, surf.sdf, oo, dv, jit)
+        else:
+            pts, hit, sdf_d = m.query_sdf_point_wocuda_wodeform(oo, dv, global_step=7 if train else None, keep_dim=True,
+                                                                jitter=None if jit is None else jit.cuda(), **rk)
+        val = (pts * c_pts.to(dev)).sum() + (sdf_d * c_sdf.to(dev)).sum()
+        val.backward()
+        res[name] = (pts.detach().cpu(), hit.cpu(), sdf_d.detach().cpu(), oo.grad.cpu(), dv.grad.cpu())
+    (p0, h0, s0, go0, gd0), (p1, h1, s1, go1, gd1) = res['oracle'], res['hip']
+    assert 0.2 < h0.float().mean() < 0.98, 'the case must hold hits and misses'
+    assert_close(s1.numpy(), s0.numpy(), rtol=1e-4, atol=2e-5, name='dense sdf row')
+    same = (h0 == h1)
+    assert same.float().mean() > 0.99
+    assert_close(p1[same & h0].numpy(), p0[same & h0].numpy(), rtol=1e-4, atol=2e-5, name='surface points')
+    # rays whose crossing sits within rounding distance of an interval end (z0 zeroed on one side only) are excluded
+    stable = same & ((p0 - p1).abs().amax(-1) < 1e-3)
+    assert stable.float().mean() > 0.98
+    assert_close(go1[stable].numpy(), go0[stable].numpy(), rtol=2e-3, atol=1e-5, scaled=1e-3, name='d/d rays_o')
+    assert_close(gd1[stable].numpy(), gd0[stable].numpy(), rtol=2e-3, atol=1e-5, scaled=1e-3, name='d/d rays_d')
 
 
 @pytest.mark.gpu
