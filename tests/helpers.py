@@ -90,3 +90,68 @@ def assert_close_but(a, b, rtol, atol, name, frac=1e-3, loose_atol=5e-4):
     assert err.max() <= loose_atol + rtol * np.abs(b).max(), f'{name}: max abs err {err.max():.3e}'
     bad = err > atol + rtol * np.abs(b)
     assert bad.mean() <= frac, f'{name}: {bad.sum()}/{a.size} outside rtol {rtol} / atol {atol} (max abs err {err.max():.3e})'
+
+
+def assert_normals_close(a, b, name='gradient', frac=1e-4):
+    """SDF normals [M,3] of two fp32 implementations: the trilinear interpolant is continuous but its gradient jumps at cell
+    faces, so a deformed sample within rounding distance of a face (|u - round(u)| ~ 1e-5 voxels: a couple of the ~1e5
+    coordinates of a step) reads its normal from the neighbouring cell in one of them.  All rows but a fraction `frac` meet the
+    tight bound (rtol 1e-4 + 2e-5 of the largest entry); the exceptions stay below the jump a cell face can cause."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, f'{name}: shape {a.shape} vs {b.shape}'
+    err, mx = np.abs(a - b), np.abs(b).max()
+    bad = (err > 1e-5 + 1e-4 * np.abs(b) + 2e-5 * mx).any(axis=-1)
+    assert bad.mean() <= frac, f'{name}: {bad.sum()}/{bad.size} rows outside the tight bound (max abs err {err.max():.3e}, max |ref| {mx:.3e})'
+    assert err.max() <= 2e-2 * mx, f'{name}: max abs err {err.max():.3e} (max |ref| {mx:.3e})'
+
+
+def ref96_inputs(d):
+    """Inputs of tests/golden/forward_ref96.npz regenerated from the seeds it stores (the reference's real configuration:
+    96^3 voxels, 113 samples per ray, 1024 rays of 3 views 400 x 400; oracle/make_golden.py::gen_forward_ref96)."""
+    from poseprobe_amd.engine import SceneConfig
+    from poseprobe_amd.params_init import reference_like_params
+    G, H, W, nv, N = (int(d[k]) for k in ('G', 'H', 'W', 'n_views', 'n_rand'))
+    rs = syn.range_shape()
+    cfg = SceneConfig(syn.XYZ_MIN, syn.XYZ_MAX, G ** 3, stepsize=float(d['stepsize']), out_range=float(rs.max()))
+    assert cfg.n_samples == int(d['n_samples']) == 113
+    idx, jit = syn.step_randomness(nv * H * W, N, seed=int(d['batch_seed']))
+    return dict(cfg=cfg, views=syn.make_views(nv, H, W), P=reference_like_params(cfg, int(d['param_seed'])),
+                se3=syn.se3_perturbation(nv), idx=idx, jit=jit, gs=int(d['global_step']), G=G, H=H, W=W, nv=nv, N=N,
+                scene=O.Scene(syn.XYZ_MIN, syn.XYZ_MAX, G ** 3, stepsize=float(d['stepsize']), output_range=float(rs.max()),
+                              rect_size=rs.tolist()))
+
+
+def check_against_ref96(d, get, tol_pix=dict(rtol=1e-4, atol=1e-5), tol_grad=dict(rtol=1e-3, scaled=5e-5), frac=2e-3):
+    """Compare one step's results with the reference's stored outputs.  `get(name)` returns the candidate's numpy array for:
+    rgb_marched, alphainv_cum, cum_weights [N], depth, weights [M], raw_alpha [M], raw_rgb [M,3], gradient [M,3], sdf_deform [M],
+    samples_per_ray, loss.<k>, grad.se3, grad.sdf_alpha, grad.sdf_beta, grad.rgbnet.<l>.weight|bias, grad.warp.<l>.weight|bias,
+    k0_grad (callable result: [X*Y*Z, 12] rows for given voxel ids), k0g.sum / abs_sum / n_touched."""
+    assert np.array_equal(get('samples_per_ray'), d['samples_per_ray']), 'per-ray in-bbox sample counts (indices) differ'
+    assert_close_but(get('rgb_marched'), d['out.rgb_marched'], name='rgb_marched', frac=frac, **tol_pix)
+    assert_close_but(get('alphainv_cum'), d['out.alphainv_cum'], name='alphainv_cum', frac=frac, **tol_pix)
+    assert_close_but(get('cum_weights'), d['out.cum_weights'][:, 0], name='cum_weights', frac=frac, **tol_pix)
+    assert_close_but(get('depth'), d['out.depth'], name='depth', frac=frac, **tol_pix)
+    assert_close_but(get('weights')[::8], d['out8.weights'][:, 0], rtol=1e-4, atol=1e-6, name='weights')
+    assert_close_but(get('raw_alpha')[::8], d['out8.raw_alpha'][:, 0], rtol=1e-4, atol=1e-6, name='raw_alpha')
+    assert_close_but(get('raw_rgb')[::8], d['out8.raw_rgb'], rtol=1e-4, atol=1e-5, name='raw_rgb')
+    assert_normals_close(get('gradient')[::8], d['out8.gradient'], frac=0.0 if frac == 0.0 else 2e-4)
+    assert_close_but(get('sdf_deform')[::8], d['out8.sdf_deform'][:, 0], rtol=1e-4, atol=1e-6, name='sdf_deform')
+    for k in ('img_render', 'weight_entropy_last', 'grad_constraint', 'grad_deform_constraint', 'sdf_correct_constraint',
+              'sdf_deform_constraint', 'mask_render'):
+        assert_close(np.float32(get('loss.' + k)), d['loss.' + k], rtol=2e-4, atol=1e-7, name='loss.' + k)
+    assert_close(get('grad.se3'), d['grad.se3'], atol=1e-6, name='g.se3', **tol_grad)
+    assert_close(get('grad.sdf_alpha'), d['grad.sdf_alpha'], atol=1e-7, name='g.sdf_alpha', **tol_grad)
+    assert_close(get('grad.sdf_beta'), d['grad.sdf_beta'], atol=1e-7, name='g.sdf_beta', **tol_grad)
+    for li in range(4):
+        for w in ('weight', 'bias'):
+            assert_close(get(f'grad.rgbnet.{li}.{w}'), d[f'grad.rgbnet.{li}.{w}'], atol=1e-8, name=f'g.rgbnet{li}.{w}', **tol_grad)
+    for li in range(5):
+        for w in ('weight', 'bias'):
+            assert_close(get(f'grad.warp.{li}.{w}'), d[f'grad.warp.{li}.{w}'], atol=2e-7, name=f'g.warp{li}.{w}', **tol_grad)
+    rows = get('k0_grad')(d['k0g.voxels'])
+    assert_close(rows, d['k0g.values'], atol=1e-9, name='k0 gradient at the stored voxels', **tol_grad)
+    # support size: a contribution that underflows to exact zero in one implementation only may differ, nothing else
+    assert abs(int(get('k0g.n_touched')) - int(d['k0g.n_touched'])) <= 1e-3 * int(d['k0g.n_touched']), 'number of voxels with a colour-grid gradient'
+    assert_close(np.float64(get('k0g.abs_sum')), d['k0g.abs_sum'], rtol=1e-4, name='sum |k0 grad|')
+    assert_close(np.float64(get('k0g.sum')), d['k0g.sum'], rtol=1e-3, atol=1e-5 * float(d['k0g.abs_sum']), name='sum k0 grad')

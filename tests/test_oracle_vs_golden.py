@@ -80,6 +80,44 @@ def test_forward_losses_and_all_gradients(tag):
         assert_close(P['warp'][li][1].grad, d[f'grad.warp.{li}.bias'], rtol=1e-4, atol=1e-7, name=f'warp{li}.b')
 
 
+def test_oracle_step_at_the_reference_configuration_96_cubed():
+    """The reference's REAL configuration (96^3 voxels, 113 samples per ray, 1024 rays, 3 x 400 x 400 views;
+    configs/dtu_e2e/scan1.py:110): the oracle against outputs of the reference's own Python
+    (tests/golden/forward_ref96.npz), inputs regenerated from the stored seeds."""
+    from tests.helpers import check_against_ref96, ref96_inputs
+    d = load('forward_ref96.npz')
+    r = ref96_inputs(d)
+    P, views = O.params_require_grad(r['P']), r['views']
+    s3 = torch.tensor(r['se3'], requires_grad=True)
+    c2w = O.pose_invert(O.current_pose_pnp(s3, torch.tensor(views['w2c'])))
+    ro, rd, vd, target, mask = O.select_training_rays(torch.tensor(r['idx']), torch.tensor(views['images']),
+                                                      torch.tensor(views['masks']), torch.tensor(views['Ks']), c2w)
+    assert np.array_equal(ro.detach().numpy(), d['rays_o']) and np.array_equal(rd.detach().numpy(), d['rays_d'])
+    assert np.array_equal(target.numpy(), d['target'])
+    out = O.voxurf_forward(P, r['scene'], ro, rd, vd, jitter=torch.tensor(r['jit']), global_step=r['gs'])
+    S, _, loss = O.object_losses(out, target, mask, r['gs'], r['scene'].N_iters, weight_tv_k0=0.0)
+    (loss * 0.1).backward()
+    assert out['weights'].shape[0] == int(d['M'])
+    assert_close(out['k0_tv'], d['out.k0_tv'], rtol=2e-5, name='k0_tv')
+    c = lambda t: t.detach().numpy()
+    gk = P['k0'].grad[0].reshape(12, -1)
+    vals = {'samples_per_ray': out['mask'].reshape(r['N'], -1).sum(1).numpy().astype(np.int16),
+            'cum_weights': c(out['cum_weights'])[:, 0], 'grad.se3': c(s3.grad), 'grad.sdf_alpha': c(P['sdf_alpha'].grad),
+            'grad.sdf_beta': c(P['sdf_beta'].grad), 'k0_grad': lambda vox: c(gk[:, torch.tensor(vox, dtype=torch.long)].T),
+            'k0g.n_touched': int((gk.abs().amax(0) > 0).sum()), 'k0g.sum': float(gk.double().sum()),
+            'k0g.abs_sum': float(gk.double().abs().sum())}
+    for k in ('rgb_marched', 'alphainv_cum', 'depth', 'weights', 'raw_alpha', 'raw_rgb', 'gradient', 'sdf_deform'):
+        vals[k] = c(out[k])
+    for k, v in S.items():
+        vals['loss.' + k] = c(v)
+    for li in range(4):
+        vals[f'grad.rgbnet.{li}.weight'], vals[f'grad.rgbnet.{li}.bias'] = c(P['rgbnet'][li][0].grad), c(P['rgbnet'][li][1].grad)
+    for li in range(5):
+        vals[f'grad.warp.{li}.weight'], vals[f'grad.warp.{li}.bias'] = c(P['warp'][li][0].grad), c(P['warp'][li][1].grad)
+    # same arithmetic on the same host: far tighter than the GPU tolerances
+    check_against_ref96(d, vals.__getitem__, tol_pix=dict(rtol=2e-5, atol=2e-6), tol_grad=dict(rtol=2e-4, scaled=2e-6), frac=0.0)
+
+
 def test_inference_matches_reference():
     d = load('inference_g24.npz')
     scene = scene_for(d['G'])
