@@ -506,20 +506,21 @@ def main():
         def wrapper(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            fn(*a, **k)
+            r = fn(*a, **k)
             e1.record()
             events.setdefault(name, []).append((e0, e1))
+            return r
         return wrapper
 
     def staged_warp_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad, ctx=None):
         """pp_warp_bwd as its two stages (identical work: pp_warp_bwd == data then weights), so that each kernel gets its
         own event pair."""
-        ops.warp_bwd_data(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad)
-        ops.warp_bwd_weights(acts, scratch, count, capacity, params_grad)
+        stage2 = ops.warp_bwd_data(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad, ctx)
+        ops.warp_bwd_weights(acts, scratch, count, capacity, params_grad, stage2, ctx)
 
     def staged_rgbnet_bwd(params, feat, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad, ctx=None):
-        ops.rgbnet_bwd_data(params, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad)
-        ops.rgbnet_bwd_weights(feat, acts, scratch, count, capacity, params_grad)
+        stage2 = ops.rgbnet_bwd_data(params, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad, ctx)
+        ops.rgbnet_bwd_weights(feat, acts, scratch, count, capacity, params_grad, stage2, ctx)
 
     originals = {n: getattr(ops, n) for n in ('grid_tv_adam_step', 'grid_tv_adam_step_sparse', 'warp_bwd_data', 'warp_bwd',
                                               'rgbnet_bwd', 'warp_fwd', 'rgbnet_fwd', 'warp_bwd_weights', 'rgbnet_bwd_data',
@@ -569,26 +570,29 @@ def main():
 
     # the same step with every matrix product on the fp32 instructions (option mlp_split = 0): reported beside `value` so that
     # both arithmetic paths of the MLP kernels are on the record (same engine, the same pre-generated rays reused)
+    # A SECOND engine with its own pp_context (mlp_split = 0) beside the default one: options are per context, nothing
+    # process-wide is flipped.
     from poseprobe_amd import _lib
     split_default = _lib.get_option('mlp_split')
     fp32_path = None
-    if split_default and _lib.get_option('mlp_fused'):
-        _lib.set_option('mlp_split', 0)
+    if split_default and _lib.get_option('mlp_fused') and not use_dist:
+        eng32 = TrainEngine(cfg, V, H, W, N, device=dev, pose_iters=3000, options={'mlp_split': 0})
+        eng32.set_views(views['images'], views['masks'], views['Ks'], views['w2c'])
+        init_engine_params(eng32, cfg, seed=3)
+        eng32.zero_grads()
         for s in range(args.warmup):
-            eng.train_step(idx_all[s], jit_all[s], gs + total + extra + s)
+            eng32.train_step(idx_all[s], jit_all[s], gs + s)
         barrier()
         t1 = time.perf_counter()
         for s in range(args.warmup, total):
-            eng.train_step(idx_all[s], jit_all[s], gs + total + extra + s)
+            eng32.train_step(idx_all[s], jit_all[s], gs + s)
         barrier()
         dt32 = time.perf_counter() - t1
-        if use_dist:
-            t = torch.tensor([dt32], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            dt32 = float(t.item())
-        _lib.set_option('mlp_split', split_default)
+        del eng32
+        torch.cuda.empty_cache()
         fp32_path = {'value': N * world * args.steps / dt32, 'unit': 'rays/s', 'ms_per_step': dt32 / args.steps * 1e3,
-                     'what': 'the same timed loop with option mlp_split = 0: all MLP products on v_mfma_f32_32x32x2_f32'}
+                     'what': 'the same timed loop on a second engine whose pp_context has mlp_split = 0: all MLP products on '
+                             'v_mfma_f32_32x32x2_f32 (same initial parameters, same rays)'}
     hidden = 2 * 128 * 128
     flops = {'k_warp_fused_fwd': 3 * 4 * hidden, 'k_warp_fused_bwd': 3 * 4 * hidden, 'k_wgrad_chain<128> (warp)': 3 * 4 * hidden,
              'k_rgb_fused_fwd': 2 * (64 * 128 + 2 * 128 * 128), 'k_rgb_fused_bwd': 2 * (64 * 128 + 2 * 128 * 128),

@@ -18,7 +18,8 @@
  *     the last failure on the calling thread;
  *   - arguments are passed one by one rather than through per-op `pp_<op>_args` structs (SURVEY 8b sketched those): the binding
  *     derives its prototypes from this header and so checks count and type of every argument; scratch sizes come from the
- *     pp_*_workspace queries, tuning switches from pp_set_option - nothing else is process-wide.
+ *     pp_*_workspace queries, option values from the caller-owned pp_context handed to the call - the library holds no
+ *     process-wide mutable state (ABI 3; ABI 1 / 2 had pp_set_option).
  */
 #ifndef POSEPROBE_HIP_H
 #define POSEPROBE_HIP_H
@@ -37,15 +38,16 @@ typedef enum {
 } pp_status;
 
 const char* pp_last_error(void);
+/* ABI history.  1: round 1.  2: pp_loss_rays / pp_loss_samples / pp_geometry_bwd_priors gained `const float* batch_norm`
+ * in front of `stream` (the library kept answering 1 for it by mistake).  3 (this header): options moved from process-wide
+ * pp_set_option / pp_get_option into the caller-owned pp_context, which every option-dependent entry point now takes in front
+ * of `stream` (pp_rgbnet_fwd, pp_warp_fwd, pp_mlp_fwd, the four two-stage backward entry points - which also hand the bias
+ * ownership from stage 1 to stage 2 explicitly -, pp_nerf_fwd / pp_nerf_bwd, pp_grid_tv_adam_step{,_sparse});
+ * pp_scene gained `sdf_index_exact`; new: pp_sdf_crossing_dense_bwd, pp_context_set_option / pp_context_get_option.
+ * A binding MUST compare pp_abi_version() with the PP_ABI_VERSION it was built against before calling anything else
+ * (poseprobe_amd/_lib.py does): the signatures changed, so a stale caller would pass a stream where a pointer is read. */
+#define PP_ABI_VERSION 3
 int pp_abi_version(void);
-
-/* Tuning options: explicit, caller-set, process-wide integers with compiled-in defaults (the measured best on MI355X).
- * The library never reads the environment; the Python host maps PP_* environment variables onto these calls when it
- * loads the library (poseprobe_amd/_lib.py).  Names: mlp_fused, wgrad_split, grid_chunks, nerf_split, nerf_split_tn,
- * nerf_bitmask, nerf_gemm_wgs, nerf_tn_ch, nerf_tn_split_wgs, nerf_tn_wgs, nerf_bn, nerf_planes, sdf_index_exact, mlp_split, nerf_tn256, mlp_wgs, wgrad_side_wgs (meaning and ranges:
- * csrc/pp_common.h, csrc/pp_error.hip).  Thread-safe (atomic); unknown names / out-of-range values are refused. */
-int pp_set_option(const char* name, int32_t value);
-int pp_get_option(const char* name, int32_t* value);
 
 /* Static description of the voxel scene; mirrors the attributes Voxurf derives in __init__ /
  * _set_grid_resolution (lib/voxurf_coarse.py:67-68, :319-323) and the render_kwargs
@@ -64,6 +66,8 @@ typedef struct {
   int32_t k0_dim;       /* 12 */
   int32_t pos_pe;       /* 5 */
   int32_t view_pe;      /* 1 */
+  int32_t sdf_index_exact; /* 0: the custom SDF sampler forms the flat voxel index in fp32 like the reference (differs above 2^24
+                            * voxels only, lib/voxurf_coarse.py:632-647); 1: the mathematically intended index */
 } pp_scene;
 
 /* ---------------------------------------------------------------- pose: lib/camera.py:76-99,127-188;
@@ -214,15 +218,25 @@ int pp_color_feat_bwd(const pp_scene* sc, const float* k0_cl, const float* pts, 
                       int32_t capacity, const float* feat_grad, float* k0_grad_cl, float* pts_grad,
                       float* gradient_grad, float* viewdir_grad_s, void* stream);
 
-/* Optional caller-owned context (one auxiliary HIP stream + events).  When passed to the MLP backward entry points the
- * weight-gradient GEMM of every layer is forked onto the auxiliary stream and runs beside the data-gradient GEMM
- * (fork / join are event edges: the sequence stays hipGraph-capturable).  NULL = strictly sequential on `stream`. */
+/* Caller-owned context = the option values of the calls it is handed to (+ one auxiliary HIP stream with its events, created
+ * on first use).  NULL everywhere = the compiled-in defaults (the measured best on MI355X).  Options are plain integers
+ * set by name; a call reads them from ITS context for the duration of the call only, so contexts with different arithmetic
+ * coexist in one process and on concurrent threads (a context itself must not be modified while a call uses it).
+ * Names (meaning and ranges: csrc/pp_common.h, csrc/pp_error.hip):
+ *   arithmetic   mlp_split (bit mask: object-branch MLP kernels as 3 fp16 products per fp32 product; 0 = fp32 MFMA instructions),
+ *                nerf_split, nerf_split_tn (scene branch likewise), mlp_fused, wgrad_split, nerf_bitmask, nerf_planes, nerf_tn256
+ *   scheduling   side_stream, mlp_wgs, wgrad_side_wgs, grid_chunks, nerf_gemm_wgs, nerf_tn_ch, nerf_tn_split_wgs, nerf_tn_wgs, nerf_bn
+ * pp_nerf_fwd and pp_nerf_bwd of one pass (and the two stages of a two-stage backward) must see the same option values.
+ * Unknown names / out-of-range values are refused; pp_context_get_option(NULL, ...) reads the defaults. */
 int pp_context_create(void** ctx);
 int pp_context_destroy(void* ctx);
-/* Layer-fused chains (Voxurf shapes): with a context the weight-gradient kernel of pp_rgbnet_bwd / pp_mlp_bwd / pp_warp_bwd
- * is launched on the auxiliary stream and NOT joined before the call returns, so that the caller's next (small) kernels
- * run beside it.  Call pp_context_join before `scratch` is reused, before params_grad is read, and at most 4 forks
- * apart: it makes `stream` wait for every deferred launch issued so far. */
+int pp_context_set_option(void* ctx, const char* name, int32_t value);
+int pp_context_get_option(const void* ctx, const char* name, int32_t* value);
+/* Option side_stream = 1 (2: rgbnet only): the weight-gradient kernel of pp_rgbnet_bwd / pp_mlp_bwd / pp_warp_bwd is launched
+ * on the context's auxiliary stream and NOT joined before the call returns, so that the caller's next (small) kernels run
+ * beside it (fork / join are event edges: the sequence stays hipGraph-capturable).  Call pp_context_join before `scratch` is
+ * reused, before params_grad is read, and at most 4 forks apart: it makes `stream` wait for every deferred launch issued so
+ * far.  With side_stream = 0 (default) everything is strictly sequential on `stream` and pp_context_join does nothing. */
 int pp_context_join(void* ctx, void* stream);
 
 /* ---------------------------------------------------------------- MLPs on the matrix cores (fp32 MFMA).
@@ -233,7 +247,7 @@ int pp_context_join(void* ctx, void* stream);
  * accepted with the default split-precision forward kernel (option mlp_split bit 4), refused otherwise. */
 #define PP_RGBNET_PARAMS (128 * 64 + 128 + 2 * (128 * 128 + 128) + 3 * 128 + 3)
 int pp_rgbnet_fwd(const float* params, const float* feat, const int32_t* count, int32_t capacity, float* acts,
-                  float* rgb, void* stream);
+                  float* rgb, void* ctx, void* stream);
 int pp_rgbnet_bwd(const float* params, const float* feat, const float* acts, const float* rgb,
                   const float* rgb_grad, const int32_t* count, int32_t capacity, float* scratch /*[3][cap][128] + 49152*/,
                   float* params_grad /*atomic +=*/, float* feat_grad, void* ctx /*pp_context or NULL*/, void* stream);
@@ -245,7 +259,7 @@ int pp_rgbnet_bwd(const float* params, const float* feat, const float* acts, con
  * acts[4][cap*4][128] (NULL: forward only, as for pp_rgbnet_fwd; option mlp_split bit 1); out[M,4,4] (x out_range). */
 #define PP_WARP_PARAMS (128 * 3 + 128 + 3 * (128 * 128 + 128) + 4 * 128 + 4)
 int pp_warp_fwd(const float* params, const float* pts, const int32_t* count, int32_t capacity, float out_range,
-                float* acts, float* out, void* stream);
+                float* acts, float* out, void* ctx, void* stream);
 int pp_warp_bwd(const float* params, const float* pts, const float* acts, const float* out_grad,
                 const int32_t* count, int32_t capacity, float out_range, float* scratch /*[3][cap*4][128] + 49152*/,
                 float* params_grad /*atomic +=*/, float* pts_grad /* += */, void* ctx /*pp_context or NULL*/,
@@ -260,17 +274,19 @@ int pp_mlp_workspace(int32_t in_ld, int32_t n_gemm, int32_t capacity, int64_t* a
  * PP_ERR_UNSUPPORTED): stage 1 = data gradients + thin-layer and bias gradients, leaves the hidden layers' output gradients
  * in `scratch`; stage 2 = the hidden layers' weight gradients from `scratch` and the stored activations.
  * pp_warp_bwd == pp_warp_bwd_data then pp_warp_bwd_weights (same for rgbnet); the split lets a caller time the kernels
- * separately, interleave other work, or put stage 2 on another stream. */
+ * separately, interleave other work, or put stage 2 on another stream.  Which stage produces the hidden layers' bias
+ * gradients depends on the kernel stage 1 ran: stage 1 reports it in *stage2_host (a HOST int32, written before the call
+ * returns) and the caller hands that value to stage 2 - stage 2 never re-derives it from its own context's options. */
 int pp_warp_bwd_data(const float* params, const float* pts, const float* acts, const float* out_grad,
                      const int32_t* count, int32_t capacity, float out_range, float* scratch, float* params_grad,
-                     float* pts_grad, void* stream);
+                     float* pts_grad, int32_t* stage2_host, void* ctx, void* stream);
 int pp_warp_bwd_weights(const float* acts, const float* scratch, const int32_t* count, int32_t capacity,
-                        float* params_grad, void* stream);
+                        float* params_grad, int32_t stage2, void* ctx, void* stream);
 int pp_rgbnet_bwd_data(const float* params, const float* acts, const float* rgb, const float* rgb_grad,
                        const int32_t* count, int32_t capacity, float* scratch, float* params_grad, float* feat_grad,
-                       void* stream);
+                       int32_t* stage2_host, void* ctx, void* stream);
 int pp_rgbnet_bwd_weights(const float* feat, const float* acts, const float* scratch, const int32_t* count,
-                          int32_t capacity, float* params_grad, void* stream);
+                          int32_t capacity, float* params_grad, int32_t stage2, void* ctx, void* stream);
 
 /* ---------------------------------------------------------------- losses: lib/losses.py:6-74 (object_losses),
  * forward values + gradients w.r.t. the render outputs in one pass.  loss_scale multiplies every gradient
@@ -302,7 +318,7 @@ int pp_loss_samples(const float* gradient, const float* grad_deform, const float
 int pp_grid_tv_adam_step(const float* p_in, float* p_out, float* grad, float* exp_avg, float* exp_avg_sq,
                          int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, int32_t x_begin,
                          int32_t x_end, float tv_scale, float grad_scale, float lr, float beta1, float beta2,
-                         float eps, int32_t step, float* tv_out, void* stream);
+                         float eps, int32_t step, float* tv_out, void* ctx, void* stream);
 /* Same pass for a SPARSE data gradient: `touched` (one byte per voxel, written by pp_k0_scatter_samples / _packed) tells
  * which voxels can hold a non-zero grad; for all others grad is neither read nor re-zeroed (96 of the 384 B/voxel).
  * Results are bit-identical to the dense pass as long as every non-zero grad voxel is marked.  `touched_clear` (the
@@ -311,7 +327,7 @@ int pp_grid_tv_adam_step_sparse(const float* p_in, float* p_out, float* grad, fl
                                 int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, int32_t x_begin,
                                 int32_t x_end, float tv_scale, float grad_scale, float lr, float beta1, float beta2,
                                 float eps, int32_t step, float* tv_out, const uint8_t* touched, uint8_t* touched_clear,
-                                void* stream);
+                                void* ctx, void* stream);
 /* Flat Adam over a packed parameter buffer with per-segment learning rates: seg_end[n_seg], seg_lr[n_seg]. */
 int pp_adam_flat(float* p, float* grad, float* exp_avg, float* exp_avg_sq, int32_t n, const int32_t* seg_end,
                  const float* seg_lr, int32_t n_seg, float grad_scale, float beta1, float beta2, float eps,
@@ -393,7 +409,7 @@ int pp_feat_generic_bwd_k0(const pp_scene* sc, const float* pts, const uint8_t* 
  * scratch [3][cap][128] + 16384. */
 int pp_mlp_fwd(const float* params, const float* feat, int32_t in_ld, int32_t n_gemm, const int32_t* count,
                int32_t capacity, const float* logit_add, int32_t logit_add_ld, float* acts, float* out,
-               void* stream);
+               void* ctx, void* stream);
 int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld, int32_t n_gemm, const float* acts,
                const float* out, const float* out_grad, const int32_t* count, int32_t capacity, float* scratch,
                float* params_grad, float* feat_grad, float* logit_add_grad, int32_t logit_add_ld, void* ctx,
@@ -420,18 +436,18 @@ int pp_march_dvgo_fwd(const float* alpha, const float* rgb, const float* step_w,
  * Workspaces in floats from pp_nerf_workspace(R * S, R, &acts, &scratch).
  * Arithmetic: fp32 operands and accumulation; the forward / data-gradient / weight-gradient matrix products are evaluated as
  * three fp16 products per fp32 product (error against fp64 equal to the fp32 matrix instructions'); options
- * nerf_split = 0 / nerf_split_tn = 0 (pp_set_option) select the fp32 matrix instructions instead. */
+ * nerf_split = 0 / nerf_split_tn = 0 (of the context handed to the call) select the fp32 matrix instructions instead. */
 int pp_nerf_layout(int64_t* offsets);
 int pp_nerf_workspace(int64_t n_samples, int64_t n_rays, int64_t* acts_floats, int64_t* scratch_floats);
 int pp_nerf_fwd(const float* params, const float* center, const float* ray, const float* depth, const float* bands,
                 const int32_t* count, int32_t n_rays, int32_t n_samples, float* acts, float* rgb_samples,
-                float* density_samples, void* stream);
+                float* density_samples, void* ctx, void* stream);
 /* Backward of pp_nerf_fwd: params_grad is ACCUMULATED into (zero it first); g_center[R,3] and g_ray[R,3] are overwritten
  * (g_ray holds the point and view-direction paths; the compositing path is pp_nerf_composite_bwd's g_ray). */
 int pp_nerf_bwd(const float* params, const float* ray, const float* depth, const int32_t* count, int32_t n_rays,
                 int32_t n_samples, const float* acts, const float* rgb_samples,
                 const float* g_rgb_samples, const float* g_density_samples, float* scratch, float* params_grad,
-                float* g_center, float* g_ray, void* stream);
+                float* g_center, float* g_ray, void* ctx, void* stream);
 /* composite (:290-343): rgb[R,3] (+ 1 - opacity when white_bg), depth[R], opacity[R], weights[R,S], all_cumulated[R]
  * (= T at the second-to-last sample), rgb_var[R], depth_var[R] (the two variances are forward-only outputs). */
 int pp_nerf_composite_fwd(const float* rgb_samples, const float* density_samples, const float* depth, const float* ray,

@@ -131,7 +131,7 @@ class _NerfSamples(torch.autograd.Function):
         # a pass that may be differentiated keeps its own activations until its backward has run (the caching allocator
         # recycles the block afterwards); anything else shares the per-shape block
         acts = ws.new_acts() if any(ctx.needs_input_grad) else ws.acts
-        ops.nerf_fwd(net.flat, center, ray, depth, net.band_weights(), ws.count, R, S, acts, rgb_s, dens)
+        ops.nerf_fwd(net.flat, center, ray, depth, net.band_weights(), ws.count, R, S, acts, rgb_s, dens, net.ctx)
         ctx.net, ctx.ws, ctx.acts = net, ws, acts
         ctx.save_for_backward(ray, depth, rgb_s)
         return rgb_s, dens
@@ -147,7 +147,7 @@ class _NerfSamples(torch.autograd.Function):
         pgrad = torch.zeros_like(net.flat)
         g_center, g_ray = torch.empty(R, 3, **f), torch.empty(R, 3, **f)
         ops.nerf_bwd(net.flat, ray, depth, ws.count, R, S, acts, rgb_s, g_rgb_s.contiguous().float(),
-                     g_dens.contiguous().float(), ws.scratch, pgrad, g_center, g_ray)
+                     g_dens.contiguous().float(), ws.scratch, pgrad, g_center, g_ray, net.ctx)
         return (None, g_center, g_ray, None, *net._views(pgrad))
 
 
@@ -182,9 +182,12 @@ class NeRF(torch.nn.Module):
 
     L_3D, L_VIEW = 10, 4
 
-    def __init__(self, opt, is_fine_network=False, device='cuda'):
+    def __init__(self, opt, is_fine_network=False, device='cuda', options=None):
+        """options: {name: value} of a private pp_context for this network's kernels (e.g. {'nerf_split': 0}: every product on
+        the fp32 MFMA instructions); None = the host's default context."""
         super().__init__()
         self.opt = opt
+        self.ctx = ops.Context(**options) if options else None
         self._check_supported(opt, is_fine_network)
         off = ops.nerf_layout()
         self._off = off
@@ -492,7 +495,7 @@ class SceneEngine:
                                 loss=torch.zeros(256, **f), loss_i=-1)
         b = ws.step_bufs
         white = bool(net.opt.nerf.setbg_opaque or net.opt.mask_img)
-        ops.nerf_fwd(net.flat, center, ray, depth, net.band_weights(), ws.count, R, S, ws.acts, b['rgb_s'], b['dens'])
+        ops.nerf_fwd(net.flat, center, ray, depth, net.band_weights(), ws.count, R, S, ws.acts, b['rgb_s'], b['dens'], net.ctx)
         ops.nerf_composite_fwd(b['rgb_s'], b['dens'], depth, ray, R, S, white, b['rgb'], b['d'], b['op'], b['w'], b['cum'],
                                b['rv'], b['dv'])
         # 2 * huber(delta = 0.5, mean) and its gradient on the [R,3] colours in one launch; the loss lands in a ring slot (the
@@ -503,7 +506,7 @@ class SceneEngine:
         ops.nerf_composite_bwd(b['rgb_s'], b['dens'], depth, ray, b['w'], R, S, white, b['g_rgb'], b['zero_r'],
                                b['zero_r'], None, b['g_rgb_s'], b['g_dens'], b['g_ray_c'])
         ops.nerf_bwd(net.flat, ray, depth, ws.count, R, S, ws.acts, b['rgb_s'], b['g_rgb_s'], b['g_dens'], ws.scratch,
-                     state.grad, b['g_center'], b['g_ray'])
+                     state.grad, b['g_center'], b['g_ray'], net.ctx)
         state.has_grad = True
         return loss, b['g_center'], b['g_ray'] + b['g_ray_c'], b['w']
 

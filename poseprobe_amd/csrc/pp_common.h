@@ -11,8 +11,9 @@
 
 void pp_set_error(const char* fmt, ...);
 
-// Tuning options (include/poseprobe_hip.h: pp_set_option / pp_get_option).  Explicit caller-set values with compiled-in
-// defaults; the library never reads the environment.
+// Options (include/poseprobe_hip.h: pp_context_set_option / pp_context_get_option).  They are fields of a caller-owned
+// pp_context that travels with every call whose behaviour they select; a NULL context means the compiled-in defaults.
+// The library holds NO process-wide mutable state and never reads the environment.
 enum PPOption {
   PP_OPT_MLP_FUSED = 0,        // 1: layer-fused object-branch MLP kernels, 0: layer-by-layer GEMMs (A/B runs)
   PP_OPT_WGRAD_SPLIT,          // 1: split-precision weight-gradient kernels in the object branch (measured slower)
@@ -26,15 +27,37 @@ enum PPOption {
   PP_OPT_NERF_TN_WGS,          // scene branch: row splits of the fp32 weight-gradient kernel
   PP_OPT_NERF_BN,              // scene branch: 256 selects the 128 x 256 tile of the fp32 NT GEMM
   PP_OPT_NERF_PLANES,          // scene branch: 1 = activations travel as pre-split fp16 hi / lo planes (pp_gemm_planes.h)
-  PP_OPT_SDF_INDEX_EXACT,      // 1: exact voxel indices in the custom SDF sampler; 0 (default): the reference's fp32 flat index
   PP_OPT_MLP_SPLIT,            // bit mask: layer-fused object-branch MLP kernels with three fp16 products per fp32 product (pp_mlp_split.hip); 1 warp fwd, 2 warp bwd, 4 rgb fwd, 8 rgb bwd, 16 weight-gradient chains
   PP_OPT_NERF_TN256,           // scene branch: 1 = 256 x 256 weight gradients by the one-work-group-per-row-range kernel (pp_gemm_tn256.h; measured equal: 127 vs 123 us)
   PP_OPT_MLP_WGS,              // work-groups of the persistent object-branch MLP kernels (0 = one per CU); fewer leave CUs to a concurrent HBM-bound kernel
   PP_OPT_WGRAD_SIDE_WGS,       // work-groups of a weight-gradient chain kernel launched on a pp_context's auxiliary stream (0 = as on the main stream):
                                // fewer leave whole CUs to the small kernels that run beside it
+  PP_OPT_SIDE_STREAM,          // 1: the weight-gradient kernels of both object-branch MLP chains are forked onto the context's auxiliary stream
+                               // (joined by pp_context_join), 2: rgbnet's only, 0 (default): strictly sequential on the caller's stream
   PP_OPT_COUNT
 };
+
+// Caller-owned context: the option values + (created on first use) one auxiliary HIP stream with its fork / join events.
+struct PPContext {
+  int opt[PP_OPT_COUNT];
+  bool have_aux;
+  hipStream_t aux;
+  hipEvent_t fork[16], join[16];
+  int pending;                      // deferred side launches of the fused paths not yet joined (pp_context_join)
+  hipEvent_t dfork[4], djoin[4];
+};
+bool pp_context_aux(PPContext* c);   // creates the auxiliary stream + events on first use; false when HIP refuses
+
+// Every entry point that takes a `ctx` opens a scope over ITS options for the duration of the call on the calling thread;
+// the launch helpers below it read them through pp_opt().  Nothing outlives the call: two contexts with different
+// arithmetic coexist in one process, also on different threads at the same time.
+struct PPOptScope {
+  const int* prev;
+  explicit PPOptScope(const void* ctx);
+  ~PPOptScope();
+};
 int pp_opt(int id);
+int pp_num_cus();                    // compute units of the current device (queried once per process: a hardware constant)
 
 #define PP_REQUIRE(cond, msg)                                     \
   do {                                                            \
@@ -74,8 +97,8 @@ static inline SceneDev pp_scene_dev(const pp_scene* s) {
   d.S = s->n_samples; d.out_range = s->out_range; d.C = s->k0_dim; d.Lp = s->pos_pe; d.Lv = s->view_pe;
   // lib/voxurf_coarse.py:632-647 computes `iz * IW * IH + iy * IW + ix` on FLOAT tensors before .long(): beyond 2^24 voxels
   // (grids above 256^3) odd flat indices are not representable and round to a neighbouring voxel.  Reproduced by default
-  // for parity (SURVEY 8a parity hazards); option sdf_index_exact = 1 gives the exact index.
-  d.flat_f32 = ((long long)s->size[0] * s->size[1] * s->size[2] > (1ll << 24)) && pp_opt(PP_OPT_SDF_INDEX_EXACT) == 0;
+  // for parity (SURVEY 8a parity hazards); pp_scene.sdf_index_exact = 1 gives the exact index.
+  d.flat_f32 = ((long long)s->size[0] * s->size[1] * s->size[2] > (1ll << 24)) && s->sdf_index_exact == 0;
   return d;
 }
 

@@ -248,48 +248,13 @@ static const int TN_WGS = 448;
 // 128 MFMAs).  With a context the backward chains fork the weight-gradient GEMM onto an auxiliary HIP stream so the
 // two kernels co-reside on the CUs and fill each other's MFMA bubbles.  The context is explicit caller-owned state
 // (no globals); fork / join are event edges, so the sequence stays capturable in a hipGraph.
-struct PPContext {
-  hipStream_t aux;
-  hipEvent_t fork[16], join[16];
-  int pending;                      // deferred side launches of the fused paths not yet joined (pp_context_join)
-  hipEvent_t dfork[4], djoin[4];
-};
-
-extern "C" int pp_context_create(void** ctx) {
-  PP_REQUIRE(ctx, "null pointer");
-  PPContext* c = new PPContext;
-  if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess) { delete c; pp_set_error("pp_context_create: stream"); return PP_ERR_LAUNCH; }
-  for (int i = 0; i < 16; ++i) {
-    hipEventCreateWithFlags(&c->fork[i], hipEventDisableTiming);
-    hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
-  }
-  for (int i = 0; i < 4; ++i) {
-    hipEventCreateWithFlags(&c->dfork[i], hipEventDisableTiming);
-    hipEventCreateWithFlags(&c->djoin[i], hipEventDisableTiming);
-  }
-  c->pending = 0;
-  *ctx = c;
-  return PP_OK;
-}
-
-extern "C" int pp_context_destroy(void* ctx) {
-  if (!ctx) return PP_OK;
-  PPContext* c = static_cast<PPContext*>(ctx);
-  hipStreamSynchronize(c->aux);
-  for (int i = 0; i < 16; ++i) { hipEventDestroy(c->fork[i]); hipEventDestroy(c->join[i]); }
-  for (int i = 0; i < 4; ++i) { hipEventDestroy(c->dfork[i]); hipEventDestroy(c->djoin[i]); }
-  hipStreamDestroy(c->aux);
-  delete c;
-  return PP_OK;
-}
-
 // Fused paths: the weight-gradient kernel of a chain depends only on what the data-gradient kernel left in `scratch` and
 // nothing downstream needs it before the optimiser, so with a context it is launched on the auxiliary stream and NOT
 // joined here: the caller's next kernels (small, latency-bound ones: colour-feature / geometry backward, ray and pose
 // backward) run beside it, and pp_context_join() is called before the scratch buffer or the gradients are touched again.
-static hipStream_t deferred_fork(void* ctx, hipStream_t main) {
+static hipStream_t deferred_fork(void* ctx, hipStream_t main, int min_mode = 1) {
   PPContext* c = static_cast<PPContext*>(ctx);
-  if (!c || c->pending >= 4) return main;
+  if (!c || c->opt[PP_OPT_SIDE_STREAM] < min_mode || c->pending >= 4 || !pp_context_aux(c)) return main;
   hipEventRecord(c->dfork[c->pending], main);
   hipStreamWaitEvent(c->aux, c->dfork[c->pending], 0);
   return c->aux;
@@ -303,7 +268,7 @@ static void deferred_forked(void* ctx, hipStream_t used, hipStream_t main) {
 
 extern "C" int pp_context_join(void* ctx, void* stream) {
   PPContext* c = static_cast<PPContext*>(ctx);
-  if (!c) return PP_OK;
+  if (!c || !c->have_aux) return PP_OK;
   for (int i = 0; i < c->pending; ++i) hipStreamWaitEvent(pp_stream(stream), c->djoin[i], 0);
   c->pending = 0;
   return PP_OK;
@@ -314,7 +279,9 @@ struct SideLane {
   hipStream_t main;
   int n = 0;        // forks issued
   int waited = 0;   // joins already waited for
-  SideLane(void* ctx, hipStream_t m) : c(static_cast<PPContext*>(ctx)), main(m) {}
+  SideLane(void* ctx, hipStream_t m) : c(static_cast<PPContext*>(ctx)), main(m) {
+    if (c && (c->opt[PP_OPT_SIDE_STREAM] == 0 || !pp_context_aux(c))) c = nullptr;
+  }
   // stream on which the next side kernel must be launched (after everything enqueued on `main` so far)
   hipStream_t fork() {
     if (!c) return main;
@@ -350,7 +317,8 @@ static inline size_t mlp_off_out(int in_ld, int n_gemm) { return mlp_off_hidden(
 
 extern "C" int pp_mlp_fwd(const float* params, const float* feat, int32_t in_ld, int32_t n_gemm, const int32_t* count,
                           int32_t capacity, const float* logit_add, int32_t logit_add_ld, float* acts, float* out,
-                          void* stream) {
+                          void* ctx, void* stream) {
+  PPOptScope scope(ctx);
   PP_REQUIRE(params && feat && count && out, "null pointer");
   PP_REQUIRE(capacity > 0 && in_ld % 32 == 0 && in_ld <= 128 && n_gemm >= 1 && n_gemm <= 8, "bad sizes");
   // acts == NULL: forward only (no backward pass will follow: the activations are not written) - the split-precision fused kernel only
@@ -383,6 +351,7 @@ extern "C" int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld,
                           const float* out, const float* out_grad, const int32_t* count, int32_t capacity,
                           float* scratch, float* params_grad, float* feat_grad, float* logit_add_grad,
                           int32_t logit_add_ld, void* ctx, void* stream) {
+  PPOptScope scope(ctx);
   PP_REQUIRE(params && feat && acts && out && out_grad && count && scratch && params_grad, "null pointer");
   PP_REQUIRE(capacity > 0 && in_ld % 32 == 0 && in_ld <= 128 && n_gemm >= 1 && n_gemm <= 8, "bad sizes");
   hipStream_t st = pp_stream(stream);
@@ -393,7 +362,7 @@ extern "C" int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld,
     else pp_launch_rgb_fused_bwd(params, acts, out, out_grad, count, capacity, scratch, params_grad, feat_grad, logit_add_grad,
                                  logit_add_ld, st);
     const size_t FLS = (size_t)capacity * 128;
-    hipStream_t ws = deferred_fork(ctx, st);
+    hipStream_t ws = deferred_fork(ctx, st, 1);
     pp_launch_wgrad_chain(scratch, acts + FLS, params_grad + RGF_W2, scratch + FLS, acts, params_grad + RGF_W1,
                           scratch + 2 * FLS, feat, params_grad + RGF_W0, 64, count, 1, capacity, ws,
                           sb ? params_grad + RGF_B2 : nullptr, sb ? params_grad + RGF_B1 : nullptr, sb ? params_grad + RGF_B0 : nullptr,
@@ -407,7 +376,7 @@ extern "C" int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld,
   float* cur = scratch;
   float* nxt = scratch + LS;
   float* wt = scratch + 2 * LS;      // one transposed weight matrix at a time (128*128 floats)
-  dim3 g(gemm_grid(capacity, PP_GEMM_BM, ctx != nullptr)), gt(TN_WGS), b(256);
+  dim3 g(gemm_grid(capacity, PP_GEMM_BM, side.c != nullptr)), gt(TN_WGS), b(256);
   const size_t oo = mlp_off_out(in_ld, n_gemm);
   hipLaunchKernelGGL(k_rgb_out_bwd, dim3(pp_div_up(capacity, STRIP)), b, 0, st, params + oo, acts + (n_gemm - 1) * LS, out,
                      out_grad, count, capacity, cur, params_grad + oo, params_grad + oo + 3 * 128, logit_add_grad,
@@ -440,8 +409,8 @@ extern "C" int pp_mlp_bwd(const float* params, const float* feat, int32_t in_ld,
 
 // rgbnet of the Voxurf configuration = generic MLP with a 64-wide (57 used) input and three 128-wide layers.
 extern "C" int pp_rgbnet_fwd(const float* params, const float* feat, const int32_t* count, int32_t capacity,
-                             float* acts, float* rgb, void* stream) {
-  return pp_mlp_fwd(params, feat, 64, 3, count, capacity, nullptr, 0, acts, rgb, stream);
+                             float* acts, float* rgb, void* ctx, void* stream) {
+  return pp_mlp_fwd(params, feat, 64, 3, count, capacity, nullptr, 0, acts, rgb, ctx, stream);
 }
 
 extern "C" int pp_rgbnet_bwd(const float* params, const float* feat, const float* acts, const float* rgb,
@@ -453,7 +422,8 @@ extern "C" int pp_rgbnet_bwd(const float* params, const float* feat, const float
 }
 
 extern "C" int pp_warp_fwd(const float* params, const float* pts, const int32_t* count, int32_t capacity,
-                           float out_range, float* acts, float* out, void* stream) {
+                           float out_range, float* acts, float* out, void* ctx, void* stream) {
+  PPOptScope scope(ctx);
   PP_REQUIRE(params && pts && count && out, "null pointer");
   PP_REQUIRE(capacity > 0, "capacity<=0");
   PP_REQUIRE(acts || (mlp_fused_enabled() && (pp_opt(PP_OPT_MLP_SPLIT) & 1)),
@@ -485,6 +455,7 @@ extern "C" int pp_warp_fwd(const float* params, const float* pts, const int32_t*
 extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* acts, const float* out_grad,
                            const int32_t* count, int32_t capacity, float out_range, float* scratch,
                            float* params_grad, float* pts_grad, void* ctx, void* stream) {
+  PPOptScope scope(ctx);
   PP_REQUIRE(params && pts && acts && out_grad && count && scratch && params_grad && pts_grad, "null pointer");
   PP_REQUIRE(capacity > 0, "capacity<=0");
   hipStream_t st = pp_stream(stream);
@@ -494,7 +465,7 @@ extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* a
     // one fused data-gradient kernel (+ thin layers), then the three weight-gradient GEMMs on the Ybar it left behind
     if (pp_opt(PP_OPT_MLP_SPLIT) & 2) pp_launch_warp_fused_bwd_s(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad, st);
     else pp_launch_warp_fused_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad, st);
-    hipStream_t ws = deferred_fork(ctx, st);
+    hipStream_t ws = deferred_fork(ctx, st, 1);                // option side_stream = 2 keeps the warp chain sequential
     const bool sb = (pp_opt(PP_OPT_MLP_SPLIT) & 2) != 0;   // the split-precision data-gradient kernel leaves b1..b3 to this one
     pp_launch_wgrad_chain(scratch, acts + 2 * LS, params_grad + WP_W3, scratch + LS, acts + LS, params_grad + WP_W2,
                           scratch + 2 * LS, acts, params_grad + WP_W1, 128, count, 4, rcap, ws,
@@ -508,7 +479,7 @@ extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* a
   float* cur = scratch;
   float* nxt = scratch + LS;
   float* wt = scratch + 2 * LS;          // transposed weights W3^T, W2^T, W1^T
-  dim3 g(gemm_grid(rcap, PP_GEMM_BM, ctx != nullptr)), gt(TN_WGS), b(256);
+  dim3 g(gemm_grid(rcap, PP_GEMM_BM, side.c != nullptr)), gt(TN_WGS), b(256);
   hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + WP_W3, wt, 128, 128);
   hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + WP_W2, wt + 16384, 128, 128);
   hipLaunchKernelGGL(k_transpose, dim3(64), b, 0, st, params + WP_W1, wt + 32768, 128, 128);
@@ -544,10 +515,12 @@ extern "C" int pp_warp_bwd(const float* params, const float* pts, const float* a
 // ------------------------------------------------------------------------------------------------------------------
 extern "C" int pp_warp_bwd_data(const float* params, const float* pts, const float* acts, const float* out_grad,
                                 const int32_t* count, int32_t capacity, float out_range, float* scratch,
-                                float* params_grad, float* pts_grad, void* stream) {
-  PP_REQUIRE(params && pts && acts && out_grad && count && scratch && params_grad && pts_grad, "null pointer");
+                                float* params_grad, float* pts_grad, int32_t* stage2_host, void* ctx, void* stream) {
+  PPOptScope scope(ctx);
+  PP_REQUIRE(params && pts && acts && out_grad && count && scratch && params_grad && pts_grad && stage2_host, "null pointer");
   PP_REQUIRE(capacity > 0, "capacity<=0");
   if (!mlp_fused_enabled()) { pp_set_error("pp_warp_bwd_data: option mlp_fused = 0 has no two-stage form"); return PP_ERR_UNSUPPORTED; }
+  *stage2_host = (pp_opt(PP_OPT_MLP_SPLIT) & 2) ? 1 : 0;       // 1: the hidden layers' bias gradients are stage 2's to produce
   if (pp_opt(PP_OPT_MLP_SPLIT) & 2)
     pp_launch_warp_fused_bwd_s(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad,
                                pp_stream(stream));
@@ -559,13 +532,14 @@ extern "C" int pp_warp_bwd_data(const float* params, const float* pts, const flo
 }
 
 extern "C" int pp_warp_bwd_weights(const float* acts, const float* scratch, const int32_t* count, int32_t capacity,
-                                   float* params_grad, void* stream) {
+                                   float* params_grad, int32_t stage2, void* ctx, void* stream) {
+  PPOptScope scope(ctx);
   PP_REQUIRE(acts && scratch && count && params_grad, "null pointer");
-  PP_REQUIRE(capacity > 0, "capacity<=0");
+  PP_REQUIRE(capacity > 0 && (stage2 == 0 || stage2 == 1), "capacity<=0 or stage2 is not what pp_warp_bwd_data returned");
   if (!mlp_fused_enabled()) { pp_set_error("pp_warp_bwd_weights: option mlp_fused = 0 has no two-stage form"); return PP_ERR_UNSUPPORTED; }
   const int rcap = capacity * 4;
   const size_t LS = (size_t)rcap * 128;
-  const bool sb = (pp_opt(PP_OPT_MLP_SPLIT) & 2) != 0;     // see pp_warp_bwd
+  const bool sb = stage2 != 0;     // who owns b1..b3 was decided by stage 1 and is handed over explicitly (never re-read from the options)
   pp_launch_wgrad_chain(scratch, acts + 2 * LS, params_grad + WP_W3, scratch + LS, acts + LS, params_grad + WP_W2,
                         scratch + 2 * LS, acts, params_grad + WP_W1, 128, count, 4, rcap, pp_stream(stream),
                         sb ? params_grad + WP_B3 : nullptr, sb ? params_grad + WP_B2 : nullptr, sb ? params_grad + WP_B1 : nullptr);
@@ -575,10 +549,12 @@ extern "C" int pp_warp_bwd_weights(const float* acts, const float* scratch, cons
 
 extern "C" int pp_rgbnet_bwd_data(const float* params, const float* acts, const float* rgb, const float* rgb_grad,
                                   const int32_t* count, int32_t capacity, float* scratch, float* params_grad,
-                                  float* feat_grad, void* stream) {
-  PP_REQUIRE(params && acts && rgb && rgb_grad && count && scratch && params_grad && feat_grad, "null pointer");
+                                  float* feat_grad, int32_t* stage2_host, void* ctx, void* stream) {
+  PPOptScope scope(ctx);
+  PP_REQUIRE(params && acts && rgb && rgb_grad && count && scratch && params_grad && feat_grad && stage2_host, "null pointer");
   PP_REQUIRE(capacity > 0, "capacity<=0");
   if (!mlp_fused_enabled()) { pp_set_error("pp_rgbnet_bwd_data: option mlp_fused = 0 has no two-stage form"); return PP_ERR_UNSUPPORTED; }
+  *stage2_host = (pp_opt(PP_OPT_MLP_SPLIT) & 8) ? 1 : 0;
   if (pp_opt(PP_OPT_MLP_SPLIT) & 8)
     pp_launch_rgb_fused_bwd_s(params, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad, nullptr, 0,
                               pp_stream(stream));
@@ -590,12 +566,13 @@ extern "C" int pp_rgbnet_bwd_data(const float* params, const float* acts, const 
 }
 
 extern "C" int pp_rgbnet_bwd_weights(const float* feat, const float* acts, const float* scratch, const int32_t* count,
-                                     int32_t capacity, float* params_grad, void* stream) {
+                                     int32_t capacity, float* params_grad, int32_t stage2, void* ctx, void* stream) {
+  PPOptScope scope(ctx);
   PP_REQUIRE(feat && acts && scratch && count && params_grad, "null pointer");
-  PP_REQUIRE(capacity > 0, "capacity<=0");
+  PP_REQUIRE(capacity > 0 && (stage2 == 0 || stage2 == 1), "capacity<=0 or stage2 is not what pp_rgbnet_bwd_data returned");
   if (!mlp_fused_enabled()) { pp_set_error("pp_rgbnet_bwd_weights: option mlp_fused = 0 has no two-stage form"); return PP_ERR_UNSUPPORTED; }
   const size_t FLS = (size_t)capacity * 128;
-  const bool sb = (pp_opt(PP_OPT_MLP_SPLIT) & 8) != 0;     // see pp_mlp_bwd
+  const bool sb = stage2 != 0;     // see pp_warp_bwd_weights
   pp_launch_wgrad_chain(scratch, acts + FLS, params_grad + RGF_W2, scratch + FLS, acts, params_grad + RGF_W1,
                         scratch + 2 * FLS, feat, params_grad + RGF_W0, 64, count, 1, capacity, pp_stream(stream),
                         sb ? params_grad + RGF_B2 : nullptr, sb ? params_grad + RGF_B1 : nullptr, sb ? params_grad + RGF_B0 : nullptr);

@@ -28,18 +28,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TILE_ROWS 64
 
 int pp_fused_wgs() {
-  const int opt = pp_opt(PP_OPT_MLP_WGS);
-  if (opt > 0) return opt < 16 ? 16 : opt;     // the weight-gradient chains share the work-groups out over three layers
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-      n = cus;
-    else
-      n = 256;
-  }
-  return n;
+  const int opt = pp_opt(PP_OPT_MLP_WGS);          // of the calling entry point's context
+  if (opt > 0) return opt < 16 ? 16 : opt;        // the weight-gradient chains share the work-groups out over three layers
+  return pp_num_cus();
 }
 
 namespace {

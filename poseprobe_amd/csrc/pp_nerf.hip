@@ -23,7 +23,6 @@
 #include "pp_gemm_split.h"
 #include "pp_gemm_planes.h"
 #include "pp_gemm_tn256.h"
-#include "pp_mlp_fused.h"      // pp_fused_wgs(): number of CUs
 
 #define NERF_L3D 10
 #define NERF_LV 4
@@ -680,7 +679,7 @@ static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, i
   dim3 b(256);
   if (!NERF_BITMASK) bits = nullptr;
   if (wimg && bits && EPI != EPI_PLAIN && Nout == 256 && (K & 31) == 0 && a_max && w_max && NERF_PLANES) {
-    const int cus = pp_fused_wgs();
+    const int cus = pp_num_cus();
     constexpr int E = (EPI == EPI_PLAIN) ? EPI_MASK : EPI;
     hipLaunchKernelGGL((k_gemm256p<E>), dim3(tiles < cus ? tiles : cus), dim3(512), 0, st, A, lda, wimg, K, bias, C, ldc, count, rows,
                        a_max, w_max, c_max, bits);
@@ -724,7 +723,7 @@ static void nerf_gemm_tn(hipStream_t st, const float* Y, int ldy, int N, const f
   if (NERF_SPLIT && NERF_SPLIT_TN && NERF_TN256 && y_max && x_max && N == 256 && Kx >= 256) {
     // all 256 x 256 outputs of a row range in one work-group (pp_gemm_tn256.h); the 64 skip columns of layer 4 go the old way
     const int tiles = pp_div_up(rows, TN256_ROWS);
-    const int grid = tiles < pp_fused_wgs() ? tiles : pp_fused_wgs();
+    const int grid = tiles < pp_num_cus() ? tiles : pp_num_cus();
     hipLaunchKernelGGL(k_gemm_tn256, dim3(grid), dim3(512), 0, st, Y, ldy, X, ldx, Wbar, ldx, bbar, count, rows, y_max, x_max);
     if (Kx > 256) nerf_gemm_tn(st, Y, ldy, N, X + 256, ldx, Kx - 256, Wbar + 256, nullptr, count, rows, y_max, x_max);
     return;
@@ -747,7 +746,8 @@ static void nerf_gemm_tn(hipStream_t st, const float* Y, int ldy, int N, const f
 
 extern "C" int pp_nerf_fwd(const float* params, const float* center, const float* ray, const float* depth,
                            const float* bands, const int32_t* count, int32_t n_rays, int32_t n_samples, float* acts,
-                           float* rgb_samples, float* density_samples, void* stream) {
+                           float* rgb_samples, float* density_samples, void* ctx, void* stream) {
+  PPOptScope scope(ctx);
   PP_REQUIRE(params && center && ray && depth && bands && count && acts && rgb_samples && density_samples, "null pointer");
   PP_REQUIRE(n_rays > 0 && n_samples > 0 && (int64_t)n_rays * n_samples < (1LL << 30), "bad sizes");
   hipStream_t st = pp_stream(stream);
@@ -794,7 +794,8 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
 extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* depth, const int32_t* count,
                            int32_t n_rays, int32_t n_samples, const float* acts, const float* rgb_samples, const float* g_rgb_samples,
                            const float* g_density_samples, float* scratch, float* params_grad, float* g_center, float* g_ray,
-                           void* stream) {
+                           void* ctx, void* stream) {
+  PPOptScope scope(ctx);
   PP_REQUIRE(params && ray && depth && count && acts && rgb_samples && g_rgb_samples && g_density_samples && scratch &&
                  params_grad && g_center && g_ray, "null pointer");
   PP_REQUIRE(n_rays > 0 && n_samples > 0 && (int64_t)n_rays * n_samples < (1LL << 30), "bad sizes");

@@ -162,7 +162,8 @@ extern "C" int pp_grid_tv_adam_step_sparse(const float* p_in, float* p_out, floa
                                     int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, int32_t x_begin, int32_t x_end,
                                     float tv_scale, float grad_scale, float lr, float beta1, float beta2, float eps,
                                     int32_t step, float* tv_out, const uint8_t* touched,
-                                            uint8_t* touched_clear, void* stream) {
+                                            uint8_t* touched_clear, void* ctx, void* stream) {
+  PPOptScope scope(ctx);
   PP_REQUIRE(p_in && p_out && grad && exp_avg && exp_avg_sq, "null pointer");
   const int32_t size[3] = {size_x, size_y, size_z};
   PP_REQUIRE(p_in != p_out, "p_in and p_out must be distinct (ping-pong) buffers");
@@ -195,9 +196,9 @@ extern "C" int pp_grid_tv_adam_step_sparse(const float* p_in, float* p_out, floa
 extern "C" int pp_grid_tv_adam_step(const float* p_in, float* p_out, float* grad, float* exp_avg, float* exp_avg_sq,
                                     int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels, int32_t x_begin,
                                     int32_t x_end, float tv_scale, float grad_scale, float lr, float beta1, float beta2,
-                                    float eps, int32_t step, float* tv_out, void* stream) {
+                                    float eps, int32_t step, float* tv_out, void* ctx, void* stream) {
   return pp_grid_tv_adam_step_sparse(p_in, p_out, grad, exp_avg, exp_avg_sq, size_x, size_y, size_z, channels, x_begin, x_end,
-                                     tv_scale, grad_scale, lr, beta1, beta2, eps, step, tv_out, nullptr, nullptr, stream);
+                                     tv_scale, grad_scale, lr, beta1, beta2, eps, step, tv_out, nullptr, nullptr, ctx, stream);
 }
 
 extern "C" int pp_grid_tv_value(const float* p, int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels,

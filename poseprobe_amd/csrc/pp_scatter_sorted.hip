@@ -112,7 +112,8 @@ int run_sorted(const pp_scene* sc, const float* src, const float* feat_grad, con
                float* k0_grad, uint8_t* touched, void* work, int64_t work_bytes, hipStream_t st) {
   const size_t pairs = (size_t)n_shards * capacity * 8;
   SortedWork w;
-  if (pairs >= 0xFFFFFFF0ull || !carve(work, work_bytes, pairs, w)) return 1;
+  // k_k0_accumulate runs 16 lanes per pair with a 32-bit thread index: pairs * 16 must stay below 2^32
+  if (pairs >= (1ull << 28) || !carve(work, work_bytes, pairs, w)) return 1;
   const SceneDev sd = pp_scene_dev(sc);
   const unsigned np = (unsigned)pairs;
   hipLaunchKernelGGL((k_k0_keys<PACKED>), dim3((np + 255) / 256), dim3(256), 0, st, sd, src, count, capacity, np, w.keys_in, w.vals_in);
@@ -126,7 +127,7 @@ int run_sorted(const pp_scene* sc, const float* src, const float* feat_grad, con
 }  // namespace
 
 extern "C" int pp_k0_scatter_sorted_workspace(int64_t n_samples, int64_t* bytes) {
-  PP_REQUIRE(bytes && n_samples > 0 && n_samples * 8 < 0xFFFFFFF0ll, "bad arguments");
+  PP_REQUIRE(bytes && n_samples > 0 && n_samples * 8 < (1ll << 28), "bad arguments (at most 2^25 - 1 sample slots)");
   const size_t pairs = (size_t)n_samples * 8;
   *bytes = (int64_t)(4 * align256(pairs * sizeof(unsigned)) + align256(sort_tmp_bytes(pairs)));
   return PP_OK;

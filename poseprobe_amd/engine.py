@@ -39,6 +39,7 @@ class SceneConfig:
     k0_dim: int = 12
     out_range: float = 1.0
     inverse_y: bool = True
+    sdf_index_exact: bool = False    # True: exact voxel index in the custom SDF sampler above 2^24 voxels (default: the reference's fp32 index)
 
     def __post_init__(self):
         # identical fp32 arithmetic to Voxurf._set_grid_resolution (voxurf_coarse.py:319-323)
@@ -48,7 +49,8 @@ class SceneConfig:
         self.voxel_size = float(vs)
         self.world_size = [int(v) for v in ((hi - lo) / vs).long().tolist()]
         self.pp = ops.make_scene(lo.tolist(), hi.tolist(), self.world_size, self.voxel_size, self.stepsize, self.near,
-                                 self.far, self.bg, self.out_range, self.k0_dim, self.posbase_pe, self.viewbase_pe)
+                                 self.far, self.bg, self.out_range, self.k0_dim, self.posbase_pe, self.viewbase_pe,
+                                 sdf_index_exact=True if self.sdf_index_exact else None)
         self.n_samples = self.pp.n_samples
 
     def s_val(self, global_step):
@@ -77,7 +79,7 @@ def dynamic_weight(w0, w1, it, total):
 class Workspace:
     """All per-ray / per-sample device buffers for N rays and `capacity` samples (default N*S)."""
 
-    def __init__(self, N, capacity, device, sample_capacity=None, backward=True, keep_activations=True):
+    def __init__(self, N, capacity, device, sample_capacity=None, backward=True, keep_activations=True, ctx=None):
         f = dict(dtype=torch.float32, device=device)
         i = dict(dtype=torch.int32, device=device)
         self.N, self.cap = N, capacity
@@ -96,7 +98,8 @@ class Workspace:
         # keep_activations=False (inference: nobody will differentiate this pass): the MLP activations are not kept when the forward kernels can run without them
         # (pp_warp_fwd / pp_rgbnet_fwd with acts = NULL: the split-precision kernels, the default): 2.5 KB per sample less to write
         from . import _lib
-        split = _lib.get_option('mlp_split') if _lib.get_option('mlp_fused') else 0
+        octx = _lib.default_context() if ctx is None else ctx          # the context the forward kernels will be called with
+        split = octx.get('mlp_split') if octx.get('mlp_fused') else 0
         self.warp_acts = e(4, capacity * 4, 128, **f) if (backward or keep_activations or not split & 1) else None
         self.warp_out = e(capacity, 16, **f)
         self.alpha, self.gradient = e(capacity, **f), e(capacity, 3, **f)
@@ -202,17 +205,15 @@ class RenderCore:
     """Forward and backward kernel chains over a Workspace.  Parameters are passed as raw device tensors:
     k0_cl [X,Y,Z,C] (channels-last), sdf [X,Y,Z], flat (FlatParams-like with .view)."""
 
-    def __init__(self, cfg: SceneConfig, use_side_stream=False):
+    def __init__(self, cfg: SceneConfig, ctx=None):
+        """ctx: the pp_context (ops.Context) every option-dependent kernel of this core is called with; None = the host's
+        default context.  Its option `side_stream` (1 / 2) runs the weight-gradient kernel of each MLP chain on the context's
+        auxiliary stream beside the small, latency-bound kernels that follow the chain's data-gradient kernel and joins it before
+        the next register-hungry MLP kernel.  Measured on MI355X (kernel trace): the overlap happens, but the small kernels only
+        get the leftover wave slots (15 -> 45 us each) and the fork / join edges cost ~10 us per chain, so the step is 1 % SLOWER:
+        off by default (PP_SIDE_STREAM=1 in the host's environment turns it on in the default context)."""
         self.cfg = cfg
-        import os
-        # With a pp_context the weight-gradient kernel of each MLP chain runs on an auxiliary stream beside the small,
-        # latency-bound kernels that follow the chain's data-gradient kernel (colour-feature / geometry backward after
-        # rgbnet; ray / pose backward after the warp net) and is joined before the next register-hungry MLP kernel.
-        # Measured on MI355X (kernel trace): the overlap happens, but the small kernels only get the leftover wave slots
-        # (15 -> 45 us each) and the fork / join edges cost ~10 us per chain, so the step is 1 % SLOWER - OFF by default,
-        # PP_SIDE_STREAM=1 turns it on for experiments.
-        self.use_side_stream = use_side_stream or os.environ.get('PP_SIDE_STREAM') in ('1', '2')
-        self.side_rgb_only = os.environ.get('PP_SIDE_STREAM') == '2'
+        self.ctx = ctx
 
     # -- forward -------------------------------------------------------------------------------------------
     def sample(self, ws, jitter):
@@ -221,13 +222,13 @@ class RenderCore:
 
     def forward(self, ws, k0_cl, sdf, sdf_ab, rgbnet_p, warp_p, inv_s, pe_w, step_w=None, before_k0_use=None):
         cfg, sc = self.cfg, self.cfg.pp
-        ops.warp_fwd(warp_p, ws.pts, ws.count, ws.cap, cfg.out_range, ws.warp_acts, ws.warp_out)
+        ops.warp_fwd(warp_p, ws.pts, ws.count, ws.cap, cfg.out_range, ws.warp_acts, ws.warp_out, self.ctx)
         ops.geometry_fwd(sc, sdf, sdf_ab, ws.pts, ws.warp_out, ws.viewdirs, ws.ray_id, ws.count, ws.cap, inv_s,
                          ws.alpha, ws.gradient, ws.sdf_final, ws.sdf_deform, ws.grad_deform)
         if before_k0_use is not None:
             before_k0_use()             # multi-GPU: the all-gather of the updated grid overlaps everything above
         ops.color_feat_fwd(sc, k0_cl, ws.pts, ws.viewdirs, ws.ray_id, ws.gradient, pe_w, ws.count, ws.cap, ws.feat)
-        ops.rgbnet_fwd(rgbnet_p, ws.feat, ws.count, ws.cap, ws.rgb_acts, ws.rgb)
+        ops.rgbnet_fwd(rgbnet_p, ws.feat, ws.count, ws.cap, ws.rgb_acts, ws.rgb, self.ctx)
         ops.march_fwd(ws.alpha, ws.rgb, ws.step if step_w is None else step_w, None, ws.ray_start, ws.N, cfg.bg,
                       ws.weights, ws.T, ws.alphainv_last, ws.i_end, ws.rgb_marched, ws.rgb_pre, ws.cum_weights,
                       ws.depth_acc, None)
@@ -245,7 +246,7 @@ class RenderCore:
             ws.g_alpha.add_(g_alpha_ext)
         if g_rgb_ext is not None:
             ws.g_rgb.add_(g_rgb_ext)
-        ctx = ops.side_context() if self.use_side_stream else None
+        ctx = self.ctx
         ops.rgbnet_bwd(rgbnet_p, ws.feat, ws.rgb_acts, ws.rgb, ws.g_rgb, ws.count, ws.cap, ws.scratch_rgb,
                        rgbnet_grad, ws.g_feat, ctx)
         ops.color_feat_bwd(sc, k0_cl, ws.pts, ws.viewdirs, ws.ray_id, ws.gradient, pe_w, ws.count, ws.cap, ws.g_feat,
@@ -266,7 +267,7 @@ class RenderCore:
                              ws.g_pts, ws.g_view_s, sdf_ab_grad)
         ops.context_join(ctx)           # rgbnet's weight-gradient kernel is done before the next register-hungry kernel
         ops.warp_bwd(warp_p, ws.pts, ws.warp_acts, ws.g_warp_out, ws.count, ws.cap, cfg.out_range, ws.scratch, warp_grad,
-                     ws.g_pts, None if getattr(self, 'side_rgb_only', False) else ctx)
+                     ws.g_pts, ctx)
         if not defer_join:
             ops.context_join(ctx)
         return ctx
@@ -279,17 +280,20 @@ class TrainEngine:
 
     def __init__(self, cfg: SceneConfig, n_views, H, W, n_rand, device='cuda', lr_pose=1e-3, lr_pose_end=1e-4,
                  pose_iters=1, lrate_decay=10, loss_scale=0.1, weight_main=1.0, weight_tv_k0=0.01, weight_mask=0.1,
-                 fix_first=True, capacity=None, x_slab=None, dist_ctx=None, deterministic_scatter=False):
+                 fix_first=True, capacity=None, x_slab=None, dist_ctx=None, deterministic_scatter=False, options=None):
         """deterministic_scatter: the k0 gradient is accumulated per voxel in sample order (sorted scatter, ~0.2 ms instead of
         0.04 ms per step) instead of by float atomics - bit-identical gradient grids for identical inputs, and bit-identical
-        replicas in the multi-GPU "samples" mode without the periodic re-broadcast."""
+        replicas in the multi-GPU "samples" mode without the periodic re-broadcast.
+        options: {name: value} of a PRIVATE pp_context for this engine's kernels (e.g. {'mlp_split': 0}: every MLP product on the
+        fp32 MFMA instructions); None = the host's default context.  Engines with different options coexist in one process."""
         self.cfg, self.dev = cfg, torch.device(device)
+        self.ctx = ops.Context(**options) if options else None
         self.deterministic_scatter = bool(deterministic_scatter)
         self._scatter_work = None
         self.V, self.H, self.W, self.N = n_views, H, W, n_rand
         cap = capacity or n_rand * cfg.n_samples
-        self.ws = Workspace(n_rand, cap, self.dev)
-        self.core = RenderCore(cfg)
+        self.ws = Workspace(n_rand, cap, self.dev, ctx=self.ctx)
+        self.core = RenderCore(cfg, ctx=self.ctx)
         X, Y, Z = cfg.world_size
         f = dict(dtype=torch.float32, device=self.dev)
         self.k0 = [torch.zeros(X, Y, Z, cfg.k0_dim, **f), torch.zeros(X, Y, Z, cfg.k0_dim, **f)]   # ping-pong
@@ -428,7 +432,7 @@ class TrainEngine:
                            k0_grad, P.view('sdf_ab', 'grad'), P.view('rgbnet', 'grad'), P.view('warp', 'grad'),
                            priors=(1.0, w_dyn, ls, ws.loss_out, batch_norm),
                            after_k0_grad=after_k0, defer_join=True)
-        ctx = ops.side_context() if self.core.use_side_stream else None
+        ctx = self.ctx
         ops.raygen_select_bwd(sc, ray_idx, self.c2w, self.intr, self.H, self.W, cfg.inverse_y, ws.rays_o, ws.rays_d,
                               ws.t_min, ws.ray_start, ws.g_pts, ws.step, ws.g_view_s, None, None, None, None, None, None,
                               None, self.c2w_grad)
@@ -473,12 +477,12 @@ class TrainEngine:
             cur = self.touch_par
             ops.grid_tv_adam_step_sparse(src, dst, self.k0_grad, self.k0_m, self.k0_v, cfg.world_size, cfg.k0_dim, xb, xe,
                                          tv_scale, grad_scale, lr_k0, 0.9, 0.99, 1e-8, n_step, self.ws.tv_out,
-                                         self.k0_touched[cur], self.k0_touched[1 - cur])
+                                         self.k0_touched[cur], self.k0_touched[1 - cur], self.ctx)
             self.touch_par = 1 - cur
             self._k0_marked = False
         else:
             ops.grid_tv_adam_step(src, dst, self.k0_grad, self.k0_m, self.k0_v, cfg.world_size, cfg.k0_dim, xb, xe, tv_scale,
-                                  grad_scale, lr_k0, 0.9, 0.99, 1e-8, n_step, self.ws.tv_out)
+                                  grad_scale, lr_k0, 0.9, 0.99, 1e-8, n_step, self.ws.tv_out, self.ctx)
         self.k0_cur = 1 - self.k0_cur
 
     def train_step(self, ray_idx, jitter, global_step, optimize_pose=True):

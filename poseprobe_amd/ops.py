@@ -44,7 +44,7 @@ def _stream():
 
 
 def make_scene(xyz_min, xyz_max, world_size, voxel_size, stepsize, near, far, bg, out_range=1.0, k0_dim=12,
-               pos_pe=5, view_pe=1):
+               pos_pe=5, view_pe=1, sdf_index_exact=None):
     sc = pp_scene()
     for i in range(3):
         sc.xyz_min[i] = float(xyz_min[i])
@@ -59,6 +59,10 @@ def make_scene(xyz_min, xyz_max, world_size, voxel_size, stepsize, near, far, bg
     sc.n_samples = int(np.linalg.norm(np.array([int(w) for w in world_size]) + 1) / stepsize) + 1
     sc.out_range = float(out_range)
     sc.k0_dim, sc.pos_pe, sc.view_pe = int(k0_dim), int(pos_pe), int(view_pe)
+    if sdf_index_exact is None:         # host-side switch (PP_SDF_INDEX_EXACT=1): the mathematically intended voxel index above 2^24 voxels
+        import os
+        sdf_index_exact = os.environ.get('PP_SDF_INDEX_EXACT') == '1'
+    sc.sdf_index_exact = int(bool(sdf_index_exact))
     return sc
 
 
@@ -201,41 +205,32 @@ def k0_scatter_packed_sorted(sc, packed, n_shards, capacity, k0_grad_cl, work, t
 
 
 # ------------------------------------------------------------------------------------------- MLPs
-def rgbnet_fwd(params, feat, count, capacity, acts, rgb):
-    _lib.call('pp_rgbnet_fwd', _f(params), _f(feat), _i(count), capacity, _f(acts), _f(rgb), _stream())
+# Every wrapper of an option-dependent entry point takes `ctx`: an _lib.Context, or None = the host's default context.
+Context = _lib.Context
+_h = _lib.handle
 
 
-_CTX = {}
+def rgbnet_fwd(params, feat, count, capacity, acts, rgb, ctx=None):
+    _lib.call('pp_rgbnet_fwd', _f(params), _f(feat), _i(count), capacity, _f(acts), _f(rgb), _h(ctx), _stream())
 
 
-def side_context():
-    """Caller-owned pp_context for the current device (auxiliary stream for the weight-gradient GEMMs)."""
-    dev = torch.cuda.current_device()
-    if dev not in _CTX:
-        h = ctypes.c_void_p()
-        _lib.call('pp_context_create', ctypes.byref(h))
-        _CTX[dev] = h
-    return _CTX[dev]
-
-
-def context_join(ctx):
-    """Current stream waits for every weight-gradient kernel deferred onto the context's auxiliary stream."""
-    if ctx is not None:
-        _lib.call('pp_context_join', ctx, _stream())
+def context_join(ctx=None):
+    """Current stream waits for every weight-gradient kernel deferred onto the context's auxiliary stream (option side_stream)."""
+    _lib.call('pp_context_join', _h(ctx), _stream())
 
 
 def rgbnet_bwd(params, feat, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad, ctx=None):
     _lib.call('pp_rgbnet_bwd', _f(params), _f(feat), _f(acts), _f(rgb), _f(rgb_grad), _i(count), capacity,
-              _f(scratch), _f(params_grad), _f(feat_grad), ctx, _stream())
+              _f(scratch), _f(params_grad), _f(feat_grad), _h(ctx), _stream())
 
 
-def warp_fwd(params, pts, count, capacity, out_range, acts, out):
-    _lib.call('pp_warp_fwd', _f(params), _f(pts), _i(count), capacity, float(out_range), _f(acts), _f(out), _stream())
+def warp_fwd(params, pts, count, capacity, out_range, acts, out, ctx=None):
+    _lib.call('pp_warp_fwd', _f(params), _f(pts), _i(count), capacity, float(out_range), _f(acts), _f(out), _h(ctx), _stream())
 
 
 def warp_bwd(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad, ctx=None):
     _lib.call('pp_warp_bwd', _f(params), _f(pts), _f(acts), _f(out_grad), _i(count), capacity, float(out_range),
-              _f(scratch), _f(params_grad), _f(pts_grad), ctx, _stream())
+              _f(scratch), _f(params_grad), _f(pts_grad), _h(ctx), _stream())
 
 
 def mlp_workspaces(capacity):
@@ -248,22 +243,28 @@ def mlp_workspaces(capacity):
     return out
 
 
-def warp_bwd_data(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad):
+def warp_bwd_data(params, pts, acts, out_grad, count, capacity, out_range, scratch, params_grad, pts_grad, ctx=None):
+    """-> stage2: the value to hand to warp_bwd_weights (which stage owns the hidden layers' bias gradients)."""
+    stage2 = ctypes.c_int32()
     _lib.call('pp_warp_bwd_data', _f(params), _f(pts), _f(acts), _f(out_grad), _i(count), capacity, float(out_range),
-              _f(scratch), _f(params_grad), _f(pts_grad), _stream())
+              _f(scratch), _f(params_grad), _f(pts_grad), ctypes.byref(stage2), _h(ctx), _stream())
+    return stage2.value
 
 
-def warp_bwd_weights(acts, scratch, count, capacity, params_grad):
-    _lib.call('pp_warp_bwd_weights', _f(acts), _f(scratch), _i(count), capacity, _f(params_grad), _stream())
+def warp_bwd_weights(acts, scratch, count, capacity, params_grad, stage2, ctx=None):
+    _lib.call('pp_warp_bwd_weights', _f(acts), _f(scratch), _i(count), capacity, _f(params_grad), int(stage2), _h(ctx), _stream())
 
 
-def rgbnet_bwd_data(params, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad):
+def rgbnet_bwd_data(params, acts, rgb, rgb_grad, count, capacity, scratch, params_grad, feat_grad, ctx=None):
+    stage2 = ctypes.c_int32()
     _lib.call('pp_rgbnet_bwd_data', _f(params), _f(acts), _f(rgb), _f(rgb_grad), _i(count), capacity, _f(scratch),
-              _f(params_grad), _f(feat_grad), _stream())
+              _f(params_grad), _f(feat_grad), ctypes.byref(stage2), _h(ctx), _stream())
+    return stage2.value
 
 
-def rgbnet_bwd_weights(feat, acts, scratch, count, capacity, params_grad):
-    _lib.call('pp_rgbnet_bwd_weights', _f(feat), _f(acts), _f(scratch), _i(count), capacity, _f(params_grad), _stream())
+def rgbnet_bwd_weights(feat, acts, scratch, count, capacity, params_grad, stage2, ctx=None):
+    _lib.call('pp_rgbnet_bwd_weights', _f(feat), _f(acts), _f(scratch), _i(count), capacity, _f(params_grad), int(stage2),
+              _h(ctx), _stream())
 
 
 # ------------------------------------------------------------------------------------------- losses / optimiser
@@ -282,18 +283,18 @@ def loss_samples(gradient, grad_deform, warp_out, sdf_deform, count, capacity, w
 
 
 def grid_tv_adam_step(p_in, p_out, grad, exp_avg, exp_avg_sq, size, channels, x_begin, x_end, tv_scale, grad_scale, lr,
-                      beta1, beta2, eps, step, tv_out):
+                      beta1, beta2, eps, step, tv_out, ctx=None):
     _lib.call('pp_grid_tv_adam_step', _f(p_in), _f(p_out), _f(grad), _f(exp_avg), _f(exp_avg_sq),
               int(size[0]), int(size[1]), int(size[2]), channels, x_begin, x_end, float(tv_scale), float(grad_scale),
-              float(lr), float(beta1), float(beta2), float(eps), int(step), _f(tv_out), _stream())
+              float(lr), float(beta1), float(beta2), float(eps), int(step), _f(tv_out), _h(ctx), _stream())
 
 
 def grid_tv_adam_step_sparse(p_in, p_out, grad, exp_avg, exp_avg_sq, size, channels, x_begin, x_end, tv_scale, grad_scale,
-                             lr, beta1, beta2, eps, step, tv_out, touched, touched_clear):
+                             lr, beta1, beta2, eps, step, tv_out, touched, touched_clear, ctx=None):
     _lib.call('pp_grid_tv_adam_step_sparse', _f(p_in), _f(p_out), _f(grad), _f(exp_avg), _f(exp_avg_sq),
               int(size[0]), int(size[1]), int(size[2]), channels, x_begin, x_end, float(tv_scale), float(grad_scale),
               float(lr), float(beta1), float(beta2), float(eps), int(step), _f(tv_out), _u8(touched), _u8(touched_clear),
-              _stream())
+              _h(ctx), _stream())
 
 
 def grid_tv_value(p, size, channels, out):
@@ -343,15 +344,15 @@ def feat_generic_bwd_k0(sc, pts, sel, k0_skip, ld, count, capacity, feat_grad, k
               capacity, _f(feat_grad), _f(k0_raw_grad), _f(k0_grad_cl), _stream())
 
 
-def mlp_fwd(params, feat, in_ld, n_gemm, count, capacity, logit_add, logit_add_ld, acts, out):
+def mlp_fwd(params, feat, in_ld, n_gemm, count, capacity, logit_add, logit_add_ld, acts, out, ctx=None):
     _lib.call('pp_mlp_fwd', _f(params), _f(feat), int(in_ld), int(n_gemm), _i(count), capacity, _f(logit_add),
-              int(logit_add_ld), _f(acts), _f(out), _stream())
+              int(logit_add_ld), _f(acts), _f(out), _h(ctx), _stream())
 
 
 def mlp_bwd(params, feat, in_ld, n_gemm, acts, out, out_grad, count, capacity, scratch, params_grad, feat_grad,
             logit_add_grad, logit_add_ld, ctx=None):
     _lib.call('pp_mlp_bwd', _f(params), _f(feat), int(in_ld), int(n_gemm), _f(acts), _f(out), _f(out_grad), _i(count),
-              capacity, _f(scratch), _f(params_grad), _f(feat_grad), _f(logit_add_grad), int(logit_add_ld), ctx,
+              capacity, _f(scratch), _f(params_grad), _f(feat_grad), _f(logit_add_grad), int(logit_add_ld), _h(ctx),
               _stream())
 
 
@@ -374,15 +375,15 @@ def nerf_workspace(n_samples, n_rays):
     return a.value, s.value
 
 
-def nerf_fwd(params, center, ray, depth, bands, count, n_rays, n_samples, acts, rgb_samples, density_samples):
+def nerf_fwd(params, center, ray, depth, bands, count, n_rays, n_samples, acts, rgb_samples, density_samples, ctx=None):
     _lib.call('pp_nerf_fwd', _f(params), _f(center), _f(ray), _f(depth), _f(bands), _i(count), int(n_rays), int(n_samples),
-              _f(acts), _f(rgb_samples), _f(density_samples), _stream())
+              _f(acts), _f(rgb_samples), _f(density_samples), _h(ctx), _stream())
 
 
 def nerf_bwd(params, ray, depth, count, n_rays, n_samples, acts, rgb_samples, g_rgb_samples, g_density_samples, scratch,
-             params_grad, g_center, g_ray):
+             params_grad, g_center, g_ray, ctx=None):
     _lib.call('pp_nerf_bwd', _f(params), _f(ray), _f(depth), _i(count), int(n_rays), int(n_samples), _f(acts), _f(rgb_samples),
-              _f(g_rgb_samples), _f(g_density_samples), _f(scratch), _f(params_grad), _f(g_center), _f(g_ray), _stream())
+              _f(g_rgb_samples), _f(g_density_samples), _f(scratch), _f(params_grad), _f(g_center), _f(g_ray), _h(ctx), _stream())
 
 
 def nerf_composite_fwd(rgb_samples, density_samples, depth, ray, n_rays, n_samples, white_bg, rgb, depth_out, opacity, weights,

@@ -354,7 +354,7 @@ class Voxurf(torch.nn.Module):
                               barf_c2f=None if self.barf_c2f is None else tuple(self.barf_c2f),
                               posbase_pe=self.rgbnet_kwargs['posbase_pe'], viewbase_pe=self.rgbnet_kwargs['viewbase_pe'],
                               k0_dim=self.k0_dim, out_range=self.warp_network.output_range)
-            self._core, self._core_key = RenderCore(cfg), key
+            self._core, self._core_key = RenderCore(cfg, ctx=getattr(self, 'pp_ctx', None)), key
         return self._core
 
     def get_kwargs(self):
@@ -502,7 +502,7 @@ class Voxurf(torch.nn.Module):
                                 [(mlp[8 + 2 * k], mlp[8 + 2 * k + 1]) for k in range(5)])
             if use_deform and M > 0:
                 acts = torch.empty(4, cap * 4, 128, device=dev)
-                ops.warp_fwd(flat.view('warp'), sb['pts'], sb['count'], cap, cfg.out_range, acts, warp_out)
+                ops.warp_fwd(flat.view('warp'), sb['pts'], sb['count'], cap, cfg.out_range, acts, warp_out, core.ctx)
             alpha, grad, sdf_final = torch.empty(cap, device=dev), torch.empty(cap, 3, device=dev), torch.zeros(cap, device=dev)
             if M > 0:
                 ops.geometry_fwd(cfg.pp, self.sdf.grid[0, 0].contiguous(), flat.view('sdf_ab'), sb['pts'], warp_out,
@@ -577,7 +577,7 @@ class Voxurf(torch.nn.Module):
         sb = self._sample_dense(core, ro.detach(), rd.detach(), jitter)
         M = sb['M']
         cap = max((M + 4095) // 4096 * 4096, 4096)
-        ws = Workspace(N, cap, ro.device, sample_capacity=sb['pts'].shape[0], backward=False)
+        ws = Workspace(N, cap, ro.device, sample_capacity=sb['pts'].shape[0], backward=False, ctx=core.ctx)
         ws.M = M
         ws.rays_o, ws.rays_d, ws.viewdirs = ro.detach(), rd.detach(), vd.detach()
         for k in ('t_min', 't_max', 'ray_start', 'count', 'pts', 'ray_id', 'step_k', 'step'):
@@ -625,7 +625,7 @@ class Voxurf(torch.nn.Module):
         ops.sample_var(cfg.pp, ro, rd, sc, t_min, t_max, n_steps, ray_start, count, pts, ray_id, step_id)
         M = int(count.item())
         cap = max((M + 4095) // 4096 * 4096, 4096)
-        ws = Workspace(N, cap, dev, sample_capacity=sc, backward=False, keep_activations=False)
+        ws = Workspace(N, cap, dev, sample_capacity=sc, backward=False, keep_activations=False, ctx=core.ctx)
         ws.M = M
         ws.rays_o, ws.rays_d, ws.viewdirs = ro, rd, vd
         ws.t_min, ws.t_max, ws.ray_start, ws.count, ws.pts, ws.ray_id, ws.step_k = t_min, t_max, ray_start, count, pts, ray_id, step_id

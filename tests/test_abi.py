@@ -20,17 +20,49 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f'{name} declared in the header but not exported'
     assert hasattr(L, 'pp_last_error')
     L2 = _lib.lib()
-    assert L2.pp_abi_version() == 1
+    assert L2.pp_abi_version() == _lib.header_abi_version() == 3
+    assert not hasattr(L, 'pp_set_option') and not hasattr(L, 'pp_get_option')     # no process-wide switches left in the ABI
 
 
 def test_pp_scene_struct_matches_header_layout():
     from poseprobe_amd._lib import pp_scene
-    # 6 floats + 3 ints + 5 floats + int + float + 3 ints = 19 x 4 bytes, no padding
-    assert ctypes.sizeof(pp_scene) == 19 * 4
+    # 6 floats + 3 ints + 5 floats + int + float + 4 ints = 20 x 4 bytes, no padding
+    assert ctypes.sizeof(pp_scene) == 20 * 4
     hdr = open(os.path.join(ROOT, 'include', 'poseprobe_hip.h')).read()
     body = hdr[hdr.index('typedef struct {'):hdr.index('} pp_scene;')]
     fields = re.findall(r'(?:float|int32_t)\s+(\w+)', body)
     assert fields == [f[0] for f in pp_scene._fields_]
+
+
+def test_a_stale_library_is_refused(tmp_path, monkeypatch):
+    """The binding compares pp_abi_version() with the header's PP_ABI_VERSION before anything is called (a caller
+    built against another ABI would pass its stream where a pointer is read)."""
+    from poseprobe_amd import _lib
+    hdr = tmp_path / 'poseprobe_hip.h'
+    hdr.write_text(open(_lib.HEADER).read().replace('#define PP_ABI_VERSION 3', '#define PP_ABI_VERSION 4'))
+    monkeypatch.setattr(_lib, 'HEADER', str(hdr))
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'header_abi_version', lambda path=None: 4)
+    with pytest.raises(_lib.PoseProbeError, match='ABI'):
+        _lib.lib()
+
+
+def test_options_live_in_caller_owned_contexts():
+    """No process-wide option state: two contexts hold different values side by side, the compiled-in defaults are immutable
+    (a NULL context cannot be written), unknown names and out-of-range values are refused."""
+    from poseprobe_amd import _lib
+    a, b = _lib.Context(mlp_split=0, nerf_split=0), _lib.Context()
+    assert a.get('mlp_split') == 0 and b.get('mlp_split') == 31 == _lib.library_default('mlp_split')
+    assert a.get('nerf_split') == 0 and b.get('nerf_split') == 1
+    b.set('mlp_wgs', 48)
+    assert a.get('mlp_wgs') == 0 and b.get('mlp_wgs') == 48 and _lib.library_default('mlp_wgs') == 0
+    L = _lib.lib()
+    assert L.pp_context_set_option(None, b'mlp_split', 0) == -1 and b'null context' in L.pp_last_error()
+    with pytest.raises(_lib.PoseProbeError):
+        a.set('no_such_option', 1)
+    with pytest.raises(_lib.PoseProbeError):
+        a.set('mlp_split', 64)
+    assert set(a.options()) == set(_lib.OPTION_NAMES)
 
 
 def test_null_arguments_are_rejected_with_a_message():

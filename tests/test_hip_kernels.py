@@ -22,7 +22,7 @@ def cu(x, dtype=torch.float32):
 
 def test_library_loaded_and_fails_loudly_without_gpu_tensors():
     from poseprobe_amd import _lib, ops
-    assert _lib.lib().pp_abi_version() == 1
+    assert _lib.lib().pp_abi_version() == 3
     a = torch.zeros(4)
     with pytest.raises(RuntimeError):
         ops.alpha2weight_fwd(a, a, 1, a, a, a, a)

@@ -159,6 +159,7 @@ def test_split_precision_kernels_are_as_accurate_as_the_fp32_instructions():
     M = cap = 20000
     count = torch.tensor([M], dtype=torch.int32, device=dev)
     default = _lib.get_option('mlp_split')
+    ctxs = {0: ops.Context(mlp_split=0), default: ops.Context(mlp_split=default)}     # two contexts, two arithmetics, one process
     try:
         for wscale, gscale in ((1.0, 1.0), (1e-3, 1e-6)):
             g = torch.Generator().manual_seed(17)
@@ -178,19 +179,20 @@ def test_split_precision_kernels_are_as_accurate_as_the_fp32_instructions():
             rparams = torch.zeros(rp.numel() + 60, device=dev); rparams[:rp.numel()] = rp.to(dev)
             err = {}
             for mode in (0, default):
-                _lib.set_option('mlp_split', mode)
+                cx = ctxs[mode]
                 acts = torch.zeros(4 * cap * 4 * 128, device=dev); out = torch.zeros(cap, 16, device=dev)
-                ops.warp_fwd(params, pts_h.to(dev), count, cap, OUT_RANGE, acts, out)
+                ops.warp_fwd(params, pts_h.to(dev), count, cap, OUT_RANGE, acts, out, cx)
                 e = (out.cpu().double() - ref).abs()
                 keep = ~(e > 1e-3 * ref.abs().max()).any(1)                     # samples with a flipped ReLU are not rounding error
                 racts = torch.zeros(3 * cap * 128, device=dev); rgb = torch.zeros(cap, 3, device=dev)
-                ops.rgbnet_fwd(rparams, feat_h.to(dev), count, cap, racts, rgb)
+                ops.rgbnet_fwd(rparams, feat_h.to(dev), count, cap, racts, rgb, cx)
                 # weight gradients against float64 products of THIS mode's own Ybar and X (isolates the weight-gradient kernel)
                 scratch = torch.zeros(3 * cap * 4 * 128 + 49152, device=dev)
                 wg = torch.zeros_like(params); pg = torch.zeros(cap, 3, device=dev)
-                ops.warp_bwd_data(params, pts_h.to(dev), acts, og, count, cap, OUT_RANGE, scratch, wg, pg)
+                stage2 = ops.warp_bwd_data(params, pts_h.to(dev), acts, og, count, cap, OUT_RANGE, scratch, wg, pg, cx)
+                assert stage2 == (1 if mode & 2 else 0)
                 wg.zero_()
-                ops.warp_bwd_weights(acts, scratch, count, cap, wg)
+                ops.warp_bwd_weights(acts, scratch, count, cap, wg, stage2, cx)
                 torch.cuda.synchronize()
                 X = acts.view(4, cap * 4, 128)[:, :4 * M].double().cpu()
                 Y = scratch[:3 * cap * 4 * 128].view(3, cap * 4, 128)[:, :4 * M].double().cpu()
@@ -202,7 +204,7 @@ def test_split_precision_kernels_are_as_accurate_as_the_fp32_instructions():
             for name, a, b in zip(('warp out', 'rgb', 'W3 gradient'), err[0], err[default]):
                 assert b <= 1.25 * a + 1e-12, f'{name} (weights x {wscale}, gradients x {gscale}): fp32 {a:.3e}, split {b:.3e}'
     finally:
-        _lib.set_option('mlp_split', default)
+        assert _lib.get_option('mlp_split') == default             # the host's default context was never touched
 
 
 def test_weight_gradient_kernels_follow_growing_magnitudes():
@@ -234,9 +236,9 @@ def test_weight_gradient_kernels_follow_growing_magnitudes():
     err = {}
     try:
         for mode in (default & ~16, default | 16):
-            _lib.set_option('mlp_split', mode | 2)                      # bit 2: the data-gradient kernel leaves b1..b3 to this one
+            cx = ops.Context(mlp_split=mode)
             wg = torch.zeros(50564 + 60, device=dev)
-            ops.warp_bwd_weights(acts_d, scratch_d, count, cap, wg)
+            ops.warp_bwd_weights(acts_d, scratch_d, count, cap, wg, 1, cx)      # stage2 = 1: b1..b3 are this stage's (handed over explicitly)
             torch.cuda.synchronize()
             e = []
             for l in (3, 2, 1):
@@ -246,7 +248,7 @@ def test_weight_gradient_kernels_follow_growing_magnitudes():
                 assert float((gb - refb[l]).abs().max()) <= 1e-5 * float(refb[l].abs().max()), f'bias gradient of layer {l}, mode {mode}'
             err[mode & 16] = e
     finally:
-        _lib.set_option('mlp_split', default)
+        pass
     for l, a, b in zip((3, 2, 1), err[0], err[16]):
         assert b <= 1.25 * a + 1e-9 and b < 5e-6, f'W{l} gradient: fp32 chain {a:.3e}, split chain {b:.3e}'
 
@@ -271,12 +273,8 @@ def test_forward_only_mode_gives_the_same_outputs_without_keeping_activations():
     ops.rgbnet_fwd(rgb_p, feat, count, cap, None, rgb_b)
     torch.cuda.synchronize()
     assert torch.equal(out_a[:M], out_b[:M]) and torch.equal(rgb_a[:M], rgb_b[:M])
-    old = _lib.get_option('mlp_split')
-    try:
-        _lib.set_option('mlp_split', 0)
-        with pytest.raises(_lib.PoseProbeError):
-            ops.warp_fwd(warp_p, pts, count, cap, 1.5, None, out_b)
-        with pytest.raises(_lib.PoseProbeError):
-            ops.rgbnet_fwd(rgb_p, feat, count, cap, None, rgb_b)
-    finally:
-        _lib.set_option('mlp_split', old)
+    fp32 = ops.Context(mlp_split=0)                 # the fp32-instruction kernels cannot run without the buffer
+    with pytest.raises(_lib.PoseProbeError):
+        ops.warp_fwd(warp_p, pts, count, cap, 1.5, None, out_b, fp32)
+    with pytest.raises(_lib.PoseProbeError):
+        ops.rgbnet_fwd(rgb_p, feat, count, cap, None, rgb_b, fp32)

@@ -365,25 +365,51 @@ def test_step_gradients_do_not_depend_on_work_group_counts_or_the_auxiliary_stre
     idx, jit = syn.step_randomness(V * H * W, int(d['n_rand']), seed=91)
     idx, jit = torch.tensor(idx, dtype=torch.int32, device='cuda'), torch.tensor(jit, device='cuda')
 
-    def grads(setup):
-        eng, _ = build_engine(d, pose_iters=1000)
-        setup(eng)
+    def grads(options):
+        eng, _ = build_engine(d, pose_iters=1000, options=options)
         eng.zero_grads()
         eng.render_and_grads(idx, jit, 10)
         torch.cuda.synchronize()
         return [t.detach().cpu().numpy().copy() for t in (eng.flat.grad, eng.se3_grad, eng.k0_grad)]
 
-    ref = grads(lambda eng: None)
-    old = {k: _lib.get_option(k) for k in ('mlp_wgs', 'wgrad_side_wgs')}
-    try:
-        if variant == 'mlp_wgs':
-            _lib.set_option('mlp_wgs', 48)
-            got = grads(lambda eng: None)
-        else:
-            _lib.set_option('wgrad_side_wgs', 96)
-            got = grads(lambda eng: setattr(eng.core, 'use_side_stream', True))
-    finally:
-        for k, v in old.items():
-            _lib.set_option(k, v)
+    ref = grads(None)
+    # options are per engine (a private pp_context each): nothing process-wide is touched
+    got = grads({'mlp_wgs': 48} if variant == 'mlp_wgs' else {'wgrad_side_wgs': 96, 'side_stream': 1})
     for name, a, b in zip(('mlp / alpha / beta', 'se3', 'k0'), got, ref):
         assert_close(a, b, rtol=1e-4, scaled=2e-6, name=f'{variant}: grad {name}')
+
+
+def test_two_engines_with_different_arithmetic_coexist():
+    """Options are fields of a caller-owned pp_context (SURVEY 8b "re-entrant ... no global state"): an engine on
+    the default split-precision MLP kernels and one on the fp32 MFMA instructions (options={'mlp_split': 0}) run INTERLEAVED in
+    one process; each reproduces, bit for bit, the atomics-free forward of the same engine run alone, the two arithmetics differ
+    in the last bits and agree within the parity tolerance, and the host's default context is never touched."""
+    from poseprobe_amd import _lib
+    d = load('forward_g24_s10.npz')
+    idx = torch.tensor(d['ray_idx'], dtype=torch.int32, device='cuda')
+    jit = torch.tensor(d['jitter'], device='cuda')
+    gs = int(d['global_step'])
+    before = _lib.default_context().options()
+
+    def alone(options):
+        eng, _ = build_engine(d, options=options)
+        eng.zero_grads()
+        eng.render_and_grads(idx, jit, gs)
+        torch.cuda.synchronize()
+        return eng.ws.rgb_marched.clone(), eng.ws.rgb[:int(eng.ws.count.item())].clone()
+
+    ref_split, ref_fp32 = alone(None), alone({'mlp_split': 0})
+    a, _ = build_engine(d)
+    b, _ = build_engine(d, options={'mlp_split': 0})
+    assert a.ctx is None and b.ctx.get('mlp_split') == 0
+    a.zero_grads(); b.zero_grads()
+    for _ in range(2):                                            # interleaved, same stream
+        a.render_and_grads(idx, jit, gs)
+        b.render_and_grads(idx, jit, gs)
+    torch.cuda.synchronize()
+    Ma = int(a.ws.count.item())
+    assert torch.equal(a.ws.rgb_marched, ref_split[0]) and torch.equal(a.ws.rgb[:Ma], ref_split[1])
+    assert torch.equal(b.ws.rgb_marched, ref_fp32[0]) and torch.equal(b.ws.rgb[:Ma], ref_fp32[1])
+    assert not torch.equal(a.ws.rgb[:Ma], b.ws.rgb[:Ma])          # two arithmetics ...
+    assert_close(a.ws.rgb_marched, b.ws.rgb_marched.cpu(), rtol=1e-4, atol=1e-5, name='split vs fp32 pixels')     # ... one result
+    assert _lib.default_context().options() == before

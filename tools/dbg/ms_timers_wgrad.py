@@ -12,14 +12,14 @@ g_out = rnd(cap, 16); scratch = torch.zeros(3 * cap * 4 * 128 + 49152, device=de
 wgrad = torch.zeros_like(warp_p); pgrad = torch.zeros(cap, 3, device=dev)
 _lib.set_option('mlp_split', 31)
 ops.warp_fwd(warp_p, pts, count, cap, 1.5, acts, out)
-ops.warp_bwd_data(warp_p, pts, acts, g_out, count, cap, 1.5, scratch, wgrad, pgrad)
+stage2 = ops.warp_bwd_data(warp_p, pts, acts, g_out, count, cap, 1.5, scratch, wgrad, pgrad)
 L = _lib.lib(); buf = (ctypes.c_ulonglong * 16)()
-for _ in range(3): ops.warp_bwd_weights(acts, scratch, count, cap, wgrad)
+for _ in range(3): ops.warp_bwd_weights(acts, scratch, count, cap, wgrad, stage2)
 torch.cuda.synchronize(); L.pp_debug_read_timers(buf, 1)
 n = 10
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(n): ops.warp_bwd_weights(acts, scratch, count, cap, wgrad)
+for _ in range(n): ops.warp_bwd_weights(acts, scratch, count, cap, wgrad, stage2)
 e1.record(); torch.cuda.synchronize(); L.pp_debug_read_timers(buf, 1)
 t = [buf[i] / n / 255 for i in range(16)]
 tot = sum(t)

@@ -15,7 +15,7 @@ scratch = torch.zeros(3 * cap * 4 * 128 + 49152, device=dev)
 wgrad = torch.zeros_like(warp_p); pgrad = torch.zeros(cap, 3, device=dev)
 _lib.set_option('mlp_split', 15)
 ops.warp_fwd(warp_p, pts, count, cap, 1.5, acts, out)
-ops.warp_bwd_data(warp_p, pts, acts, g_out, count, cap, 1.5, scratch, wgrad, pgrad)
+stage2 = ops.warp_bwd_data(warp_p, pts, acts, g_out, count, cap, 1.5, scratch, wgrad, pgrad)
 R = 4 * M
 X = acts.view(4, cap * 4, 128)[:, :R].double()
 Y = scratch[:3 * cap * 4 * 128].view(3, cap * 4, 128)[:, :R].double()
@@ -25,7 +25,7 @@ ref = {3: Y[0].T @ X[2], 2: Y[1].T @ X[1], 1: Y[2].T @ X[0]}
 for mode in (15, 31):
     _lib.set_option('mlp_split', mode)
     wg = torch.zeros_like(warp_p)
-    ops.warp_bwd_weights(acts, scratch, count, cap, wg)
+    ops.warp_bwd_weights(acts, scratch, count, cap, wg, stage2)
     torch.cuda.synchronize()
     for l in (3, 2, 1):
         got = wg[off[l]:off[l] + 128 * 128].view(128, 128).double()
