@@ -164,12 +164,21 @@ def cpu_baseline_scene(V, threads, n_pix=341, S=128, reps=3):
 
 
 def cpu_baseline_psnr(dev, steps=150, G=24, HW=32, V=3, n_rand=256, seed=0, threads=None, eval_at=(), twin_eps=0.0, gs0=2000,
-                      pose_std=5e-3):
+                      pose_std=5e-3, n_eval=None, variants=None, deterministic_scatter=True, teacher_forced=False):
     """PSNR parity (BASELINE.json metric, second half): the oracle trainer (CPU) and the HIP engine start from ONE
     initialisation and see the same ray indices and jitter at every step; a smooth "teacher" scene rendered by the HIP
-    forward provides learnable 32x32 views.  Rays are drawn from 75 % of the pixels; PSNR (lib/utils.py mse2psnr =
-    -10 log10 mse, as printed at lib/recon_scene.py:654-685) of both models is taken on the 25 % held-out pixels, rendered
-    by each model's own training forward without jitter.  The HIP engine is the thing under test, the oracle the checker."""
+    forward provides learnable HW x HW views.  Rays are drawn from 75 % of the pixels; PSNR (lib/utils.py mse2psnr =
+    -10 log10 mse, as printed at lib/recon_scene.py:654-685) of both models is taken on held-out pixels (all of the other 25 %,
+    or `n_eval` of them), rendered by each model's own training forward without jitter.  The HIP engine is the thing under
+    test, the oracle the checker.
+    variants: {name: options-dict or None} - one HIP student per entry, each with its own pp_context (default: the default
+    split-precision kernels and the fp32-instruction kernels, mlp_split = 0), all trained on the same batches.
+    deterministic_scatter: the students accumulate the colour-grid gradient in sample order (no float atomics), so that run-to-run
+    noise of the HIP side is out of the comparison.
+    teacher_forced: before every step the students are put at the ORACLE's current state (parameters, Adam moments, poses,
+    learning rates) and take their own step from there; PSNR after the step is compared with the oracle's after ITS step.
+    That measures the fidelity of one optimiser step at every state of a real trajectory, without the exponential
+    amplification of rounding differences that a free-running comparison carries (see psnr_parity)."""
     import numpy as np
     import torch
     from oracle import voxurf_oracle as O
@@ -179,13 +188,15 @@ def cpu_baseline_psnr(dev, steps=150, G=24, HW=32, V=3, n_rand=256, seed=0, thre
     from poseprobe_amd.params_init import reference_like_params
     if threads:
         torch.set_num_threads(threads)
+    if variants is None:
+        variants = {'split': None, 'fp32': {'mlp_split': 0}}
     rs = syn.range_shape()
     H = W = HW
     Ks, w2c = syn.intrinsics(V, H, W), syn.cameras(V)
     cfg = SceneConfig(syn.XYZ_MIN, syn.XYZ_MAX, G ** 3, out_range=float(rs.max()))
 
-    def engine(pseed, se3, n):
-        e = TrainEngine(cfg, V, H, W, n, device=dev, pose_iters=3000)
+    def engine(pseed, se3, n, options=None, det=False):
+        e = TrainEngine(cfg, V, H, W, n, device=dev, pose_iters=3000, options=options, deterministic_scatter=det)
         e.set_views(np.zeros((V, H, W, 3), np.float32), np.ones((V, H, W, 1), np.float32), Ks, w2c)
         P = reference_like_params(cfg, pseed)
         # sdf_alpha 0.637: the mapped cube SDF has |gradient| ~ 1, so the eikonal prior agrees with the teacher's geometry
@@ -194,19 +205,21 @@ def cpu_baseline_psnr(dev, steps=150, G=24, HW=32, V=3, n_rand=256, seed=0, thre
         e.zero_grads()
         return e, P
 
-    def render_all(e, step):
-        """Every pixel of every view through the engine's training forward (no jitter) -> [V*H*W, 3], cum_weights."""
-        n_px, N = V * H * W, e.N
+    def render(e, step, pix=None):
+        """Pixels `pix` (flat [V,H,W] indices; default: all) through the engine's training forward (no jitter) -> rgb, cum_weights."""
+        pix = torch.arange(V * H * W, device=dev) if pix is None else torch.as_tensor(pix, device=dev)
+        n_px, N = pix.numel(), e.N
         out, acc = torch.zeros(n_px, 3, device=dev), torch.zeros(n_px, device=dev)
         ws, sc = e.ws, e.cfg.pp
         ops.pose_fwd(e.se3, e.w2c_init, e.refine_mask, e.w2c, e.c2w, e.jac)
+        e._upload_step_scalars(step / e.cfg.N_iters)
+        inv_s = float(np.float32(1.0) / np.float32(e.cfg.s_val(step)))
+        zero_jit = torch.zeros(N, device=dev)
         for b in range(0, n_px, N):
-            idx = (torch.arange(b, b + N, device=dev) % n_px).int()
+            idx = pix[(torch.arange(b, b + N, device=dev) % n_px)].int()
             ops.raygen_select_fwd(sc, idx, e.c2w, e.intr, H, W, e.cfg.inverse_y, True, e.images, e.masks, ws.rays_o, ws.rays_d,
                                   ws.viewdirs, ws.target, ws.mask_px)
-            e.core.sample(ws, torch.zeros(N, device=dev))
-            e._upload_step_scalars(step / e.cfg.N_iters)
-            inv_s = float(np.float32(1.0) / np.float32(e.cfg.s_val(step)))
+            e.core.sample(ws, zero_jit)
             F = e.flat
             e.core.forward(ws, e.k0_cl, e.sdf, F.view('sdf_ab'), F.view('rgbnet'), F.view('warp'), inv_s, e.pe_w)
             n = min(N, n_px - b)
@@ -221,88 +234,142 @@ def cpu_baseline_psnr(dev, steps=150, G=24, HW=32, V=3, n_rand=256, seed=0, thre
                                     torch.linspace(-1, 1, Z, device=dev), indexing='ij')
         for c in range(12):
             teacher.k0_cl[..., c] = 0.8 * torch.sin((c % 3 + 1) * gx + 0.5 * c) * torch.cos((c % 4) * gy) + 0.3 * gz
-    img, acc = render_all(teacher, gs0)
+    img, acc = render(teacher, gs0)
     images = img.view(V, H, W, 3).cpu().numpy()
     masks = (acc > 0.5).float().view(V, H, W, 1).cpu().numpy()
     del teacher
 
     se3_0 = syn.se3_perturbation(V, std=pose_std, seed=5)
-    student, P = engine(11 + seed, se3_0, n_rand)
-    student.set_views(images, masks, Ks, w2c)
+    students, P = {}, None
+    for name, options in variants.items():
+        students[name], P = engine(11 + seed, se3_0, n_rand, options=options, det=deterministic_scatter)
+        students[name].set_views(images, masks, Ks, w2c)
     scene = O.Scene(syn.XYZ_MIN, syn.XYZ_MAX, G ** 3, output_range=float(rs.max()), rect_size=rs.tolist())
-    st = O.TrainState(P, scene, torch.tensor(w2c), torch.tensor(Ks), torch.tensor(images), torch.tensor(masks),
-                      se3_refine=torch.tensor(se3_0), pose_iters=3000)
+    t_img, t_msk, t_w2c, t_K = torch.tensor(images), torch.tensor(masks), torch.tensor(w2c), torch.tensor(Ks)
+    st = O.TrainState(P, scene, t_w2c, t_K, t_img, t_msk, se3_refine=torch.tensor(se3_0), pose_iters=3000)
     twin = None
     if twin_eps:                                                   # sensitivity probe: the SAME oracle, initial colour grid nudged by rounding-level noise
         import copy
         P2 = copy.deepcopy({k: ([(a.detach().clone(), b.detach().clone()) for a, b in v] if isinstance(v, list) else v.detach().clone())
                             for k, v in P.items()})
         P2['k0'] = P2['k0'] * (1.0 + twin_eps * torch.randn(P2['k0'].shape, generator=torch.Generator().manual_seed(99)))
-        twin = O.TrainState(P2, scene, torch.tensor(w2c), torch.tensor(Ks), torch.tensor(images), torch.tensor(masks),
-                            se3_refine=torch.tensor(se3_0), pose_iters=3000)
+        twin = O.TrainState(P2, scene, t_w2c, t_K, t_img, t_msk, se3_refine=torch.tensor(se3_0), pose_iters=3000)
     rng = np.random.RandomState(123 + seed)
     n_px = V * H * W
     perm = rng.permutation(n_px)
     held, train = np.sort(perm[:n_px // 4]), perm[n_px // 4:]
-    target = torch.tensor(images).reshape(-1, 3)[held]
+    if n_eval is not None and n_eval < len(held):
+        held = np.sort(held[rng.permutation(len(held))[:n_eval]])
+    target = t_img.reshape(-1, 3)[held]
     psnr = lambda x: float(-10.0 * torch.log10(((x - target) ** 2).mean()))
 
-    def oracle_pixels(state, gs):
+    def oracle_pixels(state, gs, chunk=2048):
         with torch.no_grad():
-            c2w = O.pose_invert(O.current_pose_pnp(state.se3, torch.tensor(w2c)))
-        ro, rd, vd, _, _ = O.select_training_rays(torch.tensor(held), torch.tensor(images), torch.tensor(masks), torch.tensor(Ks), c2w)
-        return O.voxurf_forward(state.P, scene, ro, rd, vd, jitter=None, global_step=gs)['rgb_marched'].detach()
+            c2w = O.pose_invert(O.current_pose_pnp(state.se3, t_w2c))
+        out = []
+        for b in range(0, len(held), chunk):                       # the oracle builds an autograd graph for its normals: bounded chunks
+            ro, rd, vd, _, _ = O.select_training_rays(torch.tensor(held[b:b + chunk]), t_img, t_msk, t_K, c2w)
+            out.append(O.voxurf_forward(state.P, scene, ro, rd, vd, jitter=None, global_step=gs)['rgb_marched'].detach())
+        return torch.cat(out)
+
+    def evaluate(gs):
+        row = {'psnr_oracle': psnr(oracle_pixels(st, gs))}
+        for name, e in students.items():
+            row['psnr_hip' if name == 'split' else f'psnr_hip_{name}'] = psnr(render(e, gs, held)[0].cpu())
+        if twin is not None:
+            row['psnr_oracle_twin'] = psnr(oracle_pixels(twin, gs))
+        return row
+
+    def put_at_oracle_state(e):
+        lr = {g['name']: g['lr'] for g in st.groups}
+        e.load_training_state({g['name']: (g['p'], g['m'], g['v']) for g in st.groups}, st.se3, st.pose_m, st.pose_v, st.n_step,
+                              {'k0': lr['k0'], 'rgbnet': lr['rgbnet.0.weight'], 'warp': lr['warp.0.weight'], 'sdf_ab': lr['sdf_alpha']},
+                              st.lr_pose)
 
     t_cpu = 0.0
     curve = []
     for s in range(steps):
         idx = rng.choice(train, n_rand, replace=False).astype(np.int64)
         jit = rng.rand(n_rand).astype(np.float32)
+        if teacher_forced:
+            for e in students.values():
+                put_at_oracle_state(e)
         t0 = time.time()
         st.step(torch.tensor(idx), torch.tensor(jit), gs0 + s)
         t_cpu += time.time() - t0
         if twin is not None:
             twin.step(torch.tensor(idx), torch.tensor(jit), gs0 + s)
-        student.train_step(torch.tensor(idx, dtype=torch.int32, device=dev), torch.tensor(jit, device=dev), gs0 + s)
-        if (s + 1) in eval_at:
-            row = {'step': s + 1, 'psnr_hip': psnr(render_all(student, gs0 + s + 1)[0].cpu()[held]), 'psnr_oracle': psnr(oracle_pixels(st, gs0 + s + 1))}
-            if twin is not None:
-                row['psnr_oracle_twin'] = psnr(oracle_pixels(twin, gs0 + s + 1))
-            curve.append(row)
+        for e in students.values():
+            e.train_step(torch.tensor(idx, dtype=torch.int32, device=dev), torch.tensor(jit, device=dev), gs0 + s)
+        if (s + 1) in eval_at and (s + 1) != steps:
+            curve.append(dict(step=s + 1, **evaluate(gs0 + s + 1)))
     torch.cuda.synchronize()
-    gs = gs0 + steps
-    rgb_hip = render_all(student, gs)[0].cpu()[held]
-    rgb_cpu = oracle_pixels(st, gs)
-    p_hip, p_cpu = psnr(rgb_hip), psnr(rgb_cpu)
-    out = {'psnr_hip': p_hip, 'psnr_oracle': p_cpu, 'abs_delta_db': abs(p_hip - p_cpu), 'tolerance_db': 0.1,
-           'within_tolerance': bool(abs(p_hip - p_cpu) <= 0.1), 'steps': steps, 'oracle_s_per_step': t_cpu / max(steps, 1),
-           'pixel_max_abs_diff': float((rgb_hip - rgb_cpu).abs().max()), 'curve': curve,
-           'workload': f'{G}^3 grid, {V} teacher-rendered {H}x{W} views, N_rand={n_rand}, {steps} joint steps (grid + MLPs + poses) from '
-                       f'one initialisation with identical per-step rays and jitter; PSNR on the {len(held)} held-out pixels'}
+    final = evaluate(gs0 + steps)
+    if steps in eval_at:
+        curve.append(dict(step=steps, **final))
+    first = next(iter(students))
+    p_hip, p_cpu = final['psnr_hip' if first == 'split' else f'psnr_hip_{first}'], final['psnr_oracle']
+    out = dict(final, psnr_hip=p_hip, abs_delta_db=abs(p_hip - p_cpu), tolerance_db=0.1, within_tolerance=bool(abs(p_hip - p_cpu) <= 0.1),
+               steps=steps, oracle_s_per_step=t_cpu / max(steps, 1), curve=curve, variants={k: (v or 'default') for k, v in variants.items()},
+               workload=f'{G}^3 grid, {V} teacher-rendered {H}x{W} views, N_rand={n_rand}, {steps} joint steps (grid + MLPs + poses) from '
+                        f'one initialisation with identical per-step rays and jitter; PSNR on {len(held)} held-out pixels; HIP students: '
+                        f'{", ".join(variants)}' + (' (deterministic colour-grid scatter)' if deterministic_scatter else '')
+                        + ('; TEACHER-FORCED: every HIP step starts from the oracle\'s current state' if teacher_forced else ''))
     if twin is not None:
-        p_twin = psnr(oracle_pixels(twin, gs))
-        out.update(psnr_oracle_twin=p_twin, abs_delta_oracle_vs_its_twin_db=abs(p_twin - p_cpu),
+        out.update(abs_delta_oracle_vs_its_twin_db=abs(final['psnr_oracle_twin'] - p_cpu),
                    twin='the same oracle with its initial colour grid perturbed by a relative 1e-7 (fp32 rounding level): its PSNR '
                         'gap to the unperturbed oracle is the floor below which no two fp32 implementations - or two runs of the '
                         'reference with unordered atomics - can be told apart at this horizon')
     return out
 
 
-def psnr_parity(dev, horizon=25, long_steps=100, seed=0, threads=None):
-    """PSNR-parity record for bench.py / tests.  Training this model is chaotic at the level of fp32 rounding (measured: an
-    oracle run and the same run with a 1e-7 relative nudge of the initial colour grid agree to 0.00-0.05 dB for ~25-50 steps
-    and then drift apart by 0.1-2 dB), so parity is stated where it is a property of the implementation rather than of the
-    rounding noise: `abs_delta_db` at the deterministic horizon (default 25 joint optimiser steps) must be <= 0.1 dB; at the
-    long horizon the HIP-vs-oracle gap is reported next to the oracle-vs-its-own-twin gap."""
-    r = cpu_baseline_psnr(dev, steps=long_steps, seed=seed, threads=threads, eval_at=(horizon,), twin_eps=1e-7)
-    at = r['curve'][0]
-    rec = {'psnr_hip': at['psnr_hip'], 'psnr_oracle': at['psnr_oracle'], 'abs_delta_db': abs(at['psnr_hip'] - at['psnr_oracle']),
-           'tolerance_db': 0.1, 'within_tolerance': bool(abs(at['psnr_hip'] - at['psnr_oracle']) <= 0.1), 'steps': horizon,
-           'workload': r['workload'].replace(f'{long_steps} joint steps', f'{horizon} joint steps'),
-           'long_horizon': {'steps': long_steps, 'psnr_hip': r['psnr_hip'], 'psnr_oracle': r['psnr_oracle'],
-                            'psnr_oracle_twin': r['psnr_oracle_twin'], 'abs_delta_db': r['abs_delta_db'],
-                            'abs_delta_oracle_vs_its_twin_db': r['abs_delta_oracle_vs_its_twin_db'], 'twin': r['twin']},
-           'oracle_s_per_step': r['oracle_s_per_step']}
+REFERENCE_WORKLOAD = dict(G=96, HW=400, V=3, n_rand=1024, n_eval=8192)     # configs/dtu_e2e/scan1.py:110 (96^3, 113 samples / ray)
+
+
+def psnr_parity(dev, horizon=25, long_steps=40, seed=0, threads=None, workload=None, eval_every=5):
+    """PSNR-parity record for bench.py / tests, at the reference's real configuration by default (96^3 voxels, stepsize 1.5 ->
+    113 samples per ray, N_rand 1024, three 400 x 400 views).
+
+    Training this model is chaotic at the level of fp32 rounding, and at this configuration much more so than at toy sizes:
+    the oracle and the SAME oracle with its initial colour grid nudged by a relative 1e-7 are 0.003 dB apart after 5 steps,
+    0.09 dB after 10 and 0.5-0.7 dB after 20-30 (x 30 per 5 steps; profiles/r03_psnr96_curve.txt), while the PSNR itself swings
+    by +-1 dB between evaluations (Adam's first steps move every parameter by +-lr whatever the size of its gradient).  Two fp32
+    implementations whose gradients differ by summation order (1e-4 relative, a thousand times the twin's nudge) therefore sit
+    0.2-0.7 dB apart within 5-10 FREE-RUNNING steps - as do the two arithmetic paths of the HIP kernels between themselves and
+    two runs of the reference with unordered atomics.  What an implementation can be held to is the fidelity of its optimiser
+    step at every state of a training run, so parity is PINNED teacher-forced: at each of `horizon` consecutive steps of the
+    oracle's trajectory every HIP student starts from the oracle's state (parameters, Adam moments, poses, learning rates),
+    takes its own step on the same rays and jitter, and its PSNR on held-out pixels is compared with the oracle's after ITS step:
+    `abs_delta_db` = the LARGEST gap over the evaluated steps (every `eval_every`-th and the last), required <= 0.1 dB for BOTH
+    arithmetic paths of the MLP kernels.  The free-running gaps are reported next to the oracle-vs-its-twin gap in
+    `free_running`, and the record says `parity_at_convergence: "unpinned"` (no dataset / reference checkpoint exists offline)."""
+    wl = dict(REFERENCE_WORKLOAD if workload is None else workload)
+    name_of = lambda k: k[len('psnr_hip'):].lstrip('_') or 'split'
+    evals = tuple(sorted(set(list(range(eval_every, horizon + 1, eval_every)) + [1, horizon])))
+    tf = cpu_baseline_psnr(dev, steps=horizon, seed=seed, threads=threads, eval_at=evals, teacher_forced=True, **wl)
+    gaps = {}
+    for row in tf['curve']:
+        for k, v in row.items():
+            if k.startswith('psnr_hip'):
+                gaps[name_of(k)] = max(gaps.get(name_of(k), 0.0), abs(v - row['psnr_oracle']))
+    last = tf['curve'][-1]
+    rec = {'psnr_hip': last['psnr_hip'], 'psnr_oracle': last['psnr_oracle'], 'abs_delta_db': gaps['split'],
+           'abs_delta_db_by_arithmetic': gaps, 'tolerance_db': 0.1, 'within_tolerance': bool(max(gaps.values()) <= 0.1),
+           'steps': horizon, 'evaluated_at_steps': list(evals), 'mode': 'teacher-forced (each HIP step starts from the oracle\'s state)',
+           'workload': tf['workload'], 'curve': tf['curve'], 'oracle_s_per_step': tf['oracle_s_per_step'],
+           'parity_at_convergence': 'unpinned'}
+    if long_steps:
+        r = cpu_baseline_psnr(dev, steps=long_steps, seed=seed, threads=threads, eval_at=(min(horizon, long_steps),), twin_eps=1e-7, **wl)
+        at = r['curve'][0] if r['curve'] else r
+        free = {name_of(k): abs(v - r['psnr_oracle']) for k, v in r.items() if k.startswith('psnr_hip') and isinstance(v, float)}
+        rec['long_horizon_abs_delta_db'] = free['split']
+        rec['free_running'] = {
+            'steps': long_steps, 'psnr_hip': r['psnr_hip'], 'psnr_oracle': r['psnr_oracle'], 'psnr_oracle_twin': r['psnr_oracle_twin'],
+            'abs_delta_db_by_arithmetic': free, 'abs_delta_oracle_vs_its_twin_db': r['abs_delta_oracle_vs_its_twin_db'],
+            f'at_step_{at.get("step", long_steps)}': {name_of(k) if k.startswith('psnr_hip') else k: v for k, v in at.items() if k != 'step'},
+            'twin': r['twin'],
+            'note': 'free-running trajectories decorrelate within 5-10 steps at this configuration (twin gap x 30 per 5 steps): the gap to '
+                    'the oracle is reported, not asserted - parity at convergence is unpinned'}
     return rec
 
 
@@ -425,7 +492,7 @@ def main():
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     ap.add_argument('--no-dual', action='store_true', help='skip the dual-branch (object + scene) leg')
     ap.add_argument('--no-psnr', action='store_true', help='skip the PSNR-parity leg (oracle vs HIP training run)')
-    ap.add_argument('--psnr-steps', type=int, default=100, help='long-horizon length of the PSNR-parity leg')
+    ap.add_argument('--psnr-steps', type=int, default=40, help='long-horizon length of the PSNR-parity leg (>= 25; 96^3 workload, the oracle costs ~0.5-1 s per step and runs twice: itself and its twin)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -703,7 +770,7 @@ def main():
         else:
             out['cpu_baseline'] = None
         if world == 1 and not args.no_psnr:
-            out['psnr_parity'] = psnr_parity(dev, long_steps=args.psnr_steps, threads=min(8, torch.get_num_threads()))
+            out['psnr_parity'] = psnr_parity(dev, long_steps=max(25, args.psnr_steps), threads=min(16, torch.get_num_threads()))
         else:
             out['psnr_parity'] = None
         sys.stdout.flush()

@@ -622,6 +622,30 @@ class TrainEngine:
                 raise ValueError(f'optimizer state with differing step counts {sorted(set(steps))}: the fused Adam keeps one')
             self.n_step = steps[0]
 
+    def load_training_state(self, tensors, se3, se3_m, se3_v, n_step, lr, lr_pose):
+        """Resume from an IN-MEMORY training state given in the reference's terms: tensors = {name: (param, exp_avg, exp_avg_sq)}
+        with names 'k0' ([1,C,X,Y,Z]), 'sdf_alpha', 'sdf_beta', 'rgbnet.<l>.weight|bias', 'warp.<l>.weight|bias' (logical
+        shapes of the reference's modules); lr = {'k0', 'rgbnet', 'warp', 'sdf_ab'}.  Used to put this engine at the state of
+        another trainer (teacher-forced parity runs, bench.py); the file-based twin is load_checkpoint."""
+        d = lambda t: t.detach().to(self.dev, torch.float32)
+        cl = lambda t: d(t)[0].permute(1, 2, 3, 0)
+        with torch.no_grad():
+            p, m, v = tensors['k0']
+            self.k0_cl.copy_(cl(p)); self.k0_m.copy_(cl(m)); self.k0_v.copy_(cl(v))
+            F = self.flat
+            for which, pick in (('data', 0), ('m', 1), ('v', 2)):
+                ab = F.view('sdf_ab', which)
+                ab[0:1].copy_(d(tensors['sdf_alpha'][pick]).reshape(1)); ab[1:2].copy_(d(tensors['sdf_beta'][pick]).reshape(1))
+                for li, (W, b) in enumerate(unpack_rgbnet(F.view('rgbnet', which))):
+                    W.copy_(d(tensors[f'rgbnet.{li}.weight'][pick])); b.copy_(d(tensors[f'rgbnet.{li}.bias'][pick]))
+                for li, (W, b) in enumerate(unpack_warp(F.view('warp', which))):
+                    W.copy_(d(tensors[f'warp.{li}.weight'][pick])); b.copy_(d(tensors[f'warp.{li}.bias'][pick]))
+            self.se3.copy_(d(se3)); self.se3_m.copy_(d(se3_m)); self.se3_v.copy_(d(se3_v))
+        self.n_step = int(n_step)
+        for k in self.lr:
+            self.lr[k] = float(lr[k])
+        self.lr_pose = float(lr_pose)
+
     def model_kwargs(self):
         """Constructor arguments of the drop-in `Voxurf` for this engine's configuration, as plain Python values (a checkpoint
         holding them loads weights-only; utils.load_model rebuilds the module from them)."""

@@ -4,8 +4,11 @@ steps; lib/utils.py mse2psnr).
 
 Training this model is chaotic at fp32 rounding level: the oracle and its own twin (initial colour grid nudged by a relative
 1e-7) agree to a few hundredths of a dB for the first ~25-50 optimiser steps and then drift apart by 0.1-2 dB
-(gpurun_out/psnr_sweep2.log).  Parity is therefore asserted (a) at the deterministic horizon - 0.1 dB, the
-BASELINE tolerance - and (b) at the long horizon against the chaos floor the twin measures."""
+(gpurun_out/psnr_sweep2.log).  Parity is therefore PINNED (a) at the deterministic horizon - 0.1 dB, the
+BASELINE tolerance, at the reference's real configuration (96^3, 113 samples per ray, N_rand 1024, 3 x 400 x 400) and for
+BOTH arithmetic paths of the MLP kernels - and (b) at the long horizon only against the chaos floor the twin measures; parity
+at convergence is unpinned (no dataset / reference checkpoint exists offline) and the bench record says so.
+The HIP students run with the deterministic colour-grid scatter, so the HIP side carries no atomics noise."""
 import os
 import sys
 
@@ -14,38 +17,62 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIP_KEYS = ('psnr_hip', 'psnr_hip_fp32')          # default split-precision kernels, fp32 MFMA instructions (mlp_split = 0)
 
 
 def test_psnr_of_hip_and_oracle_training_runs_agree():
+    """Three seeds at the small workload (24^3, 32 x 32 views, N_rand 256; 150 steps cost seconds): every seed and both
+    arithmetics at step 10 and 25, the long horizon against the twin floor."""
     sys.path.insert(0, ROOT)
     import bench
-    gaps, floor, late = [], [], []
+    gaps, floor, late = {k: [] for k in HIP_KEYS}, [], {k: [] for k in HIP_KEYS}
     for seed in (0, 1, 2):
         r = bench.cpu_baseline_psnr('cuda:0', steps=150, seed=seed, threads=8, eval_at=(10, 25), twin_eps=1e-7)
-        print(seed, r['curve'], r['psnr_hip'], r['psnr_oracle'], r['psnr_oracle_twin'])
+        print(seed, r['curve'], {k: r[k] for k in HIP_KEYS}, r['psnr_oracle'], r['psnr_oracle_twin'])
         for row in r['curve']:
             # step 10: every seed is still deterministic (differences ~5e-4 dB); step 25: the BASELINE tolerance.  Seed 1's
             # trajectory is unstable (its PSNR falls from 15.9 to 11.7 dB while the poses jump): there the gap grows from
             # 5e-4 dB at step 10 to 0.05-0.12 dB at step 25 for EITHER arithmetic of the MLP kernels, so at step 25 one
             # seed may exceed 0.1 dB (never 0.25 dB)
-            gap = abs(row['psnr_hip'] - row['psnr_oracle'])
-            assert gap <= (0.02 if row['step'] <= 10 else 0.25), row
-            late.append(gap) if row['step'] > 10 else None
+            for k in HIP_KEYS:
+                gap = abs(row[k] - row['psnr_oracle'])
+                assert gap <= (0.02 if row['step'] <= 10 else 0.25), (k, row)
+                if row['step'] > 10:
+                    late[k].append(gap)
             assert row['psnr_oracle'] > 10.0                    # the run is learning the teacher's views (untrained: ~8 dB)
-        gaps.append(abs(r['psnr_hip'] - r['psnr_oracle']))
         floor.append(abs(r['psnr_oracle_twin'] - r['psnr_oracle']))
-        assert np.isfinite(r['psnr_hip']) and r['psnr_hip'] > 12.0
-    assert sorted(late)[-2] <= 0.1, late                       # all seeds but at most one within the BASELINE tolerance
-    # long horizon (150 steps): the trajectories have decorrelated - the oracle differs from ITS OWN twin (initial colour grid
-    # perturbed by 1e-7) by 0.06 .. 0.40 dB, two implementations (different summation orders in every kernel, unordered atomics)
-    # by 0.2 .. 1.0 dB depending on the run.  What can be asserted is that the HIP engine behaves like a perturbation of the
-    # oracle and not like a different model: a few twin-spreads on average, and never more than 1.5 dB
-    assert np.mean(gaps) <= 0.25 + 4.0 * np.mean(floor) and max(gaps) <= 1.5, (gaps, floor)
+        for k in HIP_KEYS:
+            gaps[k].append(abs(r[k] - r['psnr_oracle']))
+            assert np.isfinite(r[k]) and r[k] > 12.0
+    for k in HIP_KEYS:
+        assert sorted(late[k])[-2] <= 0.1, (k, late[k])        # all seeds but at most one within the BASELINE tolerance
+        # long horizon (150 steps): the trajectories have decorrelated - the oracle differs from ITS OWN twin (initial colour
+        # grid perturbed by 1e-7) by 0.06 .. 0.40 dB, two implementations (different summation orders in every kernel) by
+        # 0.2 .. 1.0 dB depending on the run.  What can be asserted is that the HIP engine - in EITHER arithmetic, so a
+        # regression of the split-precision kernels cannot hide behind the chaos allowance - behaves like a perturbation of the
+        # oracle and not like a different model: a few twin-spreads on average, and never more than 1.5 dB
+        assert np.mean(gaps[k]) <= 0.25 + 4.0 * np.mean(floor) and max(gaps[k]) <= 1.5, (k, gaps[k], floor)
+    # the two arithmetics against each other: the same bound (neither is privileged)
+    both = [abs(a - b) for a, b in zip(gaps['psnr_hip'], gaps['psnr_hip_fp32'])]
+    assert max(both) <= 1.5, both
 
 
-def test_bench_psnr_parity_record():
+def test_bench_psnr_parity_record_at_the_reference_configuration():
+    """bench.py's record at 96^3 voxels / 113 samples per ray / N_rand 1024 / 3 x 400 x 400 views.  Pinned: 25 teacher-forced
+    steps (every HIP step starts from the oracle's state): the largest PSNR gap over steps 1, 5, 10, 15, 20, 25 is <= 0.1 dB
+    (measured ~1e-3) for both arithmetics.  Free-running for 30 steps: reported with the twin gap, marked unpinned - and both
+    HIP arithmetics stay within a few twin-spreads of the oracle (a different model would not)."""
     sys.path.insert(0, ROOT)
     import bench
-    rec = bench.psnr_parity('cuda:0', horizon=25, long_steps=60, threads=8)
-    assert rec['within_tolerance'] and rec['abs_delta_db'] <= 0.1, rec
-    assert {'psnr_hip', 'psnr_oracle', 'abs_delta_db', 'long_horizon'} <= set(rec)
+    rec = bench.psnr_parity('cuda:0', horizon=25, long_steps=30, threads=16)
+    print({k: v for k, v in rec.items() if k != 'curve'})
+    print(rec['curve'])
+    assert '96^3' in rec['workload'] and '400x400' in rec['workload'] and 'N_rand=1024' in rec['workload']
+    assert rec['steps'] == 25 and set(rec['abs_delta_db_by_arithmetic']) == {'split', 'fp32'} and rec['evaluated_at_steps'][-1] == 25
+    assert rec['within_tolerance'] and max(rec['abs_delta_db_by_arithmetic'].values()) <= 0.1, rec
+    assert max(rec['abs_delta_db_by_arithmetic'].values()) <= 0.02, rec      # one step from a common state: far inside the tolerance
+    assert rec['parity_at_convergence'] == 'unpinned' and 'long_horizon_abs_delta_db' in rec
+    assert {'psnr_hip', 'psnr_oracle', 'abs_delta_db', 'free_running'} <= set(rec)
+    assert all(row['psnr_oracle'] > 10.0 for row in rec['curve'])
+    fr = rec['free_running']
+    assert max(fr['abs_delta_db_by_arithmetic'].values()) <= 0.5 + 4.0 * fr['abs_delta_oracle_vs_its_twin_db'], fr
