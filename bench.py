@@ -22,6 +22,9 @@ Prints ONE JSON line on rank 0 (driver contract).  Objects besides the contract'
                     states what the default path computes
   inference         whole-view inference as the reference evaluates (lib/nvs_fun.py: 4096-ray chunks of Voxurf.inference): rays/s
   cpu_baseline      the oracle (CPU restatement, "port") timed on this host's cores for a bounded sample (N=1, rank 0)
+  roofline_step     the whole step against the HBM peak: SURVEY 8d's algorithmic bytes (and the fused / per-kernel accountings) / ms_per_step
+  dropin_train_step the reference's loop body over the drop-in modules (Voxurf.forward -> object_losses -> backward -> utils.Adam.step)
+                    on the same workload: rays/s and its ratio to the engine's step
   psnr_parity       oracle and HIP engine trained from one initialisation with the same per-step rays and jitter; PSNR of
                     both on held-out pixels and their difference (BASELINE metric: "PSNR parity", <= 0.1 dB)
 """
@@ -447,6 +450,96 @@ def dual_branch_leg(eng, idx_all, jit_all, gs, N, V, H, W, object_ms, dev, steps
     return out
 
 
+def dropin_leg(dev, cfg_engine, views, idx_all, jit_all, gs, G, H, W, V, N, engine_ms, steps=20, warmup=5):
+    """The DROP-IN train step, as INTEGRATION.md tells a maintainer to run it (lib/recon_scene.py:597-606, :649, :742-747,
+    :765-771): the reference's loop body over poseprobe_amd's module API - zero_grad, pose -> c2w, ray selection, `Voxurf.forward`,
+    `object_losses`, `loss.backward()`, per-group lr decay, `utils.Adam.step()`, pose optimiser + scheduler - on the bench
+    workload (same grid, views, rays, jitter as the engine's timed loop).  Timed like `value`; reported beside it, never as it."""
+    import numpy as np
+    import torch
+    from poseprobe_amd import camera, utils
+    from poseprobe_amd import voxurf_coarse as Model
+    from poseprobe_amd.config import ConfigDict
+    from poseprobe_amd.losses import object_losses
+    from poseprobe_amd.params_init import reference_like_params
+    from poseprobe_amd import synthetic as syn
+    rs = syn.range_shape()
+    m = Model.Voxurf(syn.XYZ_MIN, syn.XYZ_MAX, num_voxels=G ** 3, num_voxels_base=G ** 3, alpha_init=1e-2, rgbnet_dim=12,
+                     rgbnet_direct=True, rgbnet_depth=4, rgbnet_width=128, posbase_pe=5, viewbase_pe=1, geo_rgb_dim=3, s_ratio=50,
+                     s_start=0.2, barf_c2f=[0.6, 1], i_train=np.arange(V), N_iters=10000, HW=np.array([[H, W]] * V), range_shape=rs,
+                     rect_size=rs.tolist(), camera_noise=0.)
+    P = reference_like_params(cfg_engine, 3)
+    sd = m.state_dict()
+    sd['k0.grid'], sd['sdf_alpha'], sd['sdf_beta'] = P['k0'], P['sdf_alpha'], P['sdf_beta']
+    for li, key in enumerate(['rgbnet.0', 'rgbnet.2.0', 'rgbnet.3.0', 'rgbnet.4']):
+        sd[key + '.weight'], sd[key + '.bias'] = P['rgbnet'][li]
+    for li in range(5):
+        sd[f'warp_network.deform_net.net.net.{li}.0.weight'], sd[f'warp_network.deform_net.net.net.{li}.0.bias'] = P['warp'][li]
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    pm = Model.pose_model(i_train=np.arange(V), camera_noise=0.).to(dev)
+    pm.se3_refine.data.copy_(torch.tensor(syn.se3_perturbation(V)))
+    # the lrate_* keys of configs/dtu_e2e/scan1.py:87-103 (lrate_sdf > 0: the frozen template is an optimiser group of its own)
+    cfg_train = ConfigDict(lrate_decay=10, lrate_sdf=0.1, lrate_k0=1e-1, lrate_rgbnet=1e-3, lrate_warp_network=1e-3, lrate_sdf_alpha=1e-2,
+                           lrate_sdf_beta=1e-2, weight_main=1., weight_tv_k0=.01, weight_mask=.1, lr_pose=1e-3, lr_pose_end=1e-4,
+                           sched_pose='ExponentialLR')
+    opt = utils.create_optimizer_or_freeze_model(m, cfg_train, global_step=0)
+    opt_pose, sched = utils.create_optimizer_pose(pm, cfg_train, max_iter=3000)
+    imgs, msks = torch.tensor(views['images']).to(dev), torch.tensor(views['masks']).to(dev)
+    w2c_init, Ks, HWs = torch.tensor(views['w2c']).to(dev), views['Ks'], np.array([[H, W]] * V)
+    decay = 0.1 ** (1 / 10000)
+    rk = dict(near=cfg_engine.near, far=cfg_engine.far, bg=cfg_engine.bg, stepsize=cfg_engine.stepsize, inverse_y=True, flip_x=False,
+              flip_y=False)
+
+    def step(s):
+        opt.zero_grad(set_to_none=True)
+        opt_pose.zero_grad()
+        w2c, c2w = camera.current_pose_c2w(pm.se3_refine, w2c_init)
+        target, mask, ro, rd, vd = Model.select_training_rays(idx_all[s].long(), imgs, msks, c2w, HWs, Ks)
+        out = m(ro, rd, vd, use_deform=True, global_step=gs + s, jitter=jit_all[s], **rk)
+        loss = object_losses(out, cfg_train, target, mask, gs + s, 10000, True)[2]
+        (loss * 0.1).backward()
+        for g in opt.param_groups:
+            g['lr'] = g['lr'] * decay
+        opt.step()
+        opt_pose.step()
+        sched.step()
+
+    for s in range(warmup):
+        step(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(warmup, warmup + steps):
+        step(s)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    # where the time goes: the same loop once more under torch's profiler-free host clock per phase (synchronising: indicative only)
+    phases = {}
+    def clock(name, fn):
+        torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+        phases[name] = phases.get(name, 0.0) + (time.perf_counter() - t) * 1e3
+        return r
+    reps = 5
+    for s in range(warmup + steps, warmup + steps + reps):
+        clock('zero_grad', lambda: (opt.zero_grad(set_to_none=True), opt_pose.zero_grad()))
+        w2c, c2w = clock('pose', lambda: camera.current_pose_c2w(pm.se3_refine, w2c_init))
+        target, mask, ro, rd, vd = clock('ray_selection', lambda: Model.select_training_rays(idx_all[s].long(), imgs, msks, c2w, HWs, Ks))
+        out = clock('forward', lambda: m(ro, rd, vd, use_deform=True, global_step=gs + s, jitter=jit_all[s], **rk))
+        loss = clock('object_losses', lambda: object_losses(out, cfg_train, target, mask, gs + s, 10000, True)[2])
+        clock('backward', lambda: (loss * 0.1).backward())
+        for g in opt.param_groups:
+            g['lr'] = g['lr'] * decay
+        clock('adam_step', lambda: opt.step())
+        clock('pose_step', lambda: (opt_pose.step(), sched.step()))
+    del m, opt
+    torch.cuda.empty_cache()
+    return {'value': N / (ms * 1e-3), 'unit': 'rays/s', 'ms_per_step': ms, 'ratio_to_engine': engine_ms / ms,
+            'engine_ms_per_step': engine_ms,
+            'what': 'Voxurf.forward -> object_losses -> loss.backward() -> utils.Adam.step() + pose optimiser, the reference\'s loop '
+                    'body (lib/recon_scene.py:597-606, :649, :742-771) over the drop-in modules, same workload as `value`',
+            'phases_ms_synchronised': {k: v / reps for k, v in phases.items()}}
+
+
 def inference_leg(dev, G, H, W, reps=3):
     """Whole-view inference the way the reference evaluates (lib/nvs_fun.py:39-86: every pixel of a view through
     Voxurf.inference in 4096-ray chunks): rays/s for one H x W view at the bench grid, drop-in module path."""
@@ -491,6 +584,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     ap.add_argument('--no-dual', action='store_true', help='skip the dual-branch (object + scene) leg')
+    ap.add_argument('--no-dropin', action='store_true', help='skip the drop-in train step leg (Voxurf.forward -> object_losses -> backward -> utils.Adam.step)')
     ap.add_argument('--no-psnr', action='store_true', help='skip the PSNR-parity leg (oracle vs HIP training run)')
     ap.add_argument('--psnr-steps', type=int, default=40, help='long-horizon length of the PSNR-parity leg (>= 25; 96^3 workload, the oracle costs ~0.5-1 s per step and runs twice: itself and its twin)')
     args = ap.parse_args()
@@ -721,6 +815,28 @@ def main():
                   (wgrad_ms, mfma_roofline('k_wgrad_chain<128> (warp)', 'weight gradients of the three hidden warp layers in one persistent kernel', wgrad_ms))]
     dominant = max((c for c in candidates if np.isfinite(c[0])), key=lambda c: c[0])[1]
 
+    # Step-level roofline (what BASELINE's north star asks for: rays/s "as fraction of the HBM roofline"): SURVEY 8d's
+    # algorithmic bytes of one step over the step time over the HBM peak, in three accountings
+    step_ms = dt / args.steps * 1e3
+    vox = (xe - xb) * Y * Z
+    b_survey = N * 64 + M * 1216 + 528 * vox                       # unfused TV + Adam + zero-fill (528 B / voxel)
+    b_fused = N * 64 + M * 1216 + grid_bytes                       # same per-ray / per-sample terms, the grid term as the fused pass moves it
+    b_kernels = b_fused + M * sum(hbm_bytes.values())              # + the activations the six MLP kernels exchange through HBM (this partition into kernels)
+    gbs = lambda b: b / (step_ms * 1e-3) / 1e9
+    roofline_step = {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'ms_per_step': step_ms,
+                     'survey_8d': {'bytes': b_survey, 'achieved': gbs(b_survey), 'frac': gbs(b_survey) / HBM_PEAK_GBS,
+                                   'formula': 'N*64 + M*1216 + 528*G^3 (SURVEY.md 8d B_step)'},
+                     'fused': {'bytes': b_fused, 'achieved': gbs(b_fused), 'frac': gbs(b_fused) / HBM_PEAK_GBS,
+                               'formula': 'N*64 + M*1216 + (288 + 96*marked)*G^3 (the grid term as the fused TV+Adam pass moves it)'},
+                     'with_mlp_activations': {'bytes': b_kernels, 'achieved': gbs(b_kernels), 'frac': gbs(b_kernels) / HBM_PEAK_GBS,
+                                              'formula': 'fused + M * (fp32 activations the six MLP kernels exchange through HBM): the '
+                                                         'compulsory traffic of THIS partition into kernels'},
+                     'N': N, 'M': M, 'voxels': vox}
+
+    dropin = None
+    if world == 1 and not args.no_dropin:
+        dropin = dropin_leg(dev, cfg, views, idx_all, jit_all, gs, G, H, W, V, N, step_ms)
+
     dual = None
     if world == 1 and not args.no_dual:
         dual = dual_branch_leg(eng, idx_all, jit_all, gs, N, V, H, W, dt / args.steps * 1e3, dev)
@@ -734,7 +850,8 @@ def main():
         out = {
             'metric': 'rays_per_sec_train_step', 'value': N * world * args.steps / dt, 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (3xf16-split products)' if split_bits else 'f32', 'data': 'synthetic',
             'arithmetic': ('fp32 operands, accumulation and results everywhere; ' +
                            ('the 128 x 128 products of the two MLPs are evaluated as three fp16 MFMA products per fp32 product '
                             '(operands split into 11 + 11 significant bits with a power-of-two scale, fp32 accumulation): measured error '
@@ -748,7 +865,7 @@ def main():
                                    f'N_rand={N}/GPU; per-step ray permutation + jitter pre-generated on the host and resident '
                                    f'in HBM (the reference draws randperm inside the step)', 'grid': G, 'n_rand_per_gpu': N,
                        'samples_in_bbox_last_step': M, 'parallelism': par},
-            'roofline': dominant, 'roofline_grid': roofline_grid,
+            'roofline': dominant, 'roofline_step': roofline_step, 'dropin_train_step': dropin, 'roofline_grid': roofline_grid,
             'roofline_mlp': {'bound': 'mfma', 'kernel': 'warp + rgbnet MLP chains (6 layer-fused kernels: fwd / bwd-data / weight-gradient); ALGORITHMIC '
                                                         'fp32 FLOP/s of the six kernels together over the fp32 MFMA peak - the kernels listed with an fp16 pipe '
                                                         'issue three times their algorithmic FLOPs on the fp16 instructions, see `kernels`',

@@ -57,7 +57,10 @@ struct PPOptScope {
   ~PPOptScope();
 };
 int pp_opt(int id);
-int pp_num_cus();                    // compute units of the current device (queried once per process: a hardware constant)
+int pp_num_cus();
+// X-marching total-variation value / gradient pass on a channels-last grid (pp_optim.hip); false: shape not covered
+bool pp_launch_tv_march(const float* p, int X, int Y, int Z, int C, float scale, const float* g_scalar, float* grad, float* tv_out,
+                        hipStream_t st);                    // compute units of the current device (queried once per process: a hardware constant)
 
 #define PP_REQUIRE(cond, msg)                                     \
   do {                                                            \

@@ -253,8 +253,9 @@ extern "C" int pp_grid_sample_bwd(const pp_scene* sc, const float* grid_cl, int3
 extern "C" int pp_grid_tv_grad(const float* p, int32_t size_x, int32_t size_y, int32_t size_z, int32_t channels,
                                float scale, const float* g_scalar, float* grad, void* stream) {
   PP_REQUIRE(p && grad, "null pointer");
-  hipLaunchKernelGGL(k_grid_tv_grad, dim3(2048), dim3(256), 0, pp_stream(stream), p, size_x, size_y, size_z, channels,
-                     scale, g_scalar, grad);
+  if (!pp_launch_tv_march(p, size_x, size_y, size_z, channels, scale, g_scalar, grad, nullptr, pp_stream(stream)))
+    hipLaunchKernelGGL(k_grid_tv_grad, dim3(2048), dim3(256), 0, pp_stream(stream), p, size_x, size_y, size_z, channels,
+                       scale, g_scalar, grad);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }

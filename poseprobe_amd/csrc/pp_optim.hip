@@ -117,6 +117,90 @@ __global__ __launch_bounds__(256) void k_grid_tv_adam(const float4* __restrict__
   }
 }
 
+// The total-variation term ON ITS OWN for the drop-in autograd path (lib/voxurf_coarse.py:443-456, :1298-1313: k0_tv is an
+// output of Voxurf.forward and its gradient arrives through loss.backward()), in the same X-marching form as the fused pass:
+// every parameter element is fetched once, the +-y / +-z neighbours come from the plane being swept.  GRAD = false: tv_out +=
+// sum |forward differences|; GRAD = true: grad += scale * g_scalar[0] * sum of sgn over the 6 neighbours (read-modify-write,
+// non-temporal).  Per step at 160^3: value 45 us (was 102), gradient 130 us (was 385) - bench.py dropin_train_step.
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_grid_tv_march(const float4* __restrict__ p_in, int X, int Y, int Z, int q4, int n_chunks,
+                                                       int chunk_len, int n_virtual, float scale, const float* __restrict__ g_scalar,
+                                                       float4* __restrict__ grad, float* __restrict__ tv_out) {
+  __shared__ float sm[4];
+  const int plane = Y * Z * q4;
+  const float s = GRAD ? scale * (g_scalar ? g_scalar[0] : 1.f) : 0.f;
+  if (GRAD && s == 0.f) return;
+  float tv_local = 0.f;
+  // the value pass ends in ONE same-address atomic per work-group (~10 ns each): it runs a bounded number of persistent
+  // work-groups over the (tile, chunk) pairs; the gradient pass has no such tail and launches one work-group per pair
+  for (int vb = blockIdx.x; vb < n_virtual; vb += gridDim.x) {
+    const int chunk = vb % n_chunks;
+    const int tile = vb / n_chunks;
+    const int i = tile * 256 + threadIdx.x;
+    const int xs = chunk * chunk_len;
+    const int xe = min(xs + chunk_len, X);
+    if (i >= plane || xs >= xe) continue;
+    const int vox = i / q4;
+    const int z = vox % Z, y = vox / Z;
+    const int sz = q4, sy = Z * q4;
+    const bool zl = z > 0, zh = z < Z - 1, yl = y > 0, yh = y < Y - 1;
+    size_t e = (size_t)xs * plane + i;
+    float4 pm = make_float4(0.f, 0.f, 0.f, 0.f), pc = p_in[e], pn;
+    if (GRAD && xs > 0) pm = p_in[e - plane];
+    for (int x = xs; x < xe; ++x, e += plane) {
+      const bool xh = x < X - 1;
+      pn = xh ? p_in[e + plane] : pc;
+      if (GRAD) {
+        float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x > 0) acc_sgn(tv, pc, pm);
+        if (xh) acc_sgn(tv, pc, pn);
+        if (zl) acc_sgn(tv, pc, p_in[e - sz]);
+        if (yl) acc_sgn(tv, pc, p_in[e - sy]);
+        if (zh) acc_sgn(tv, pc, p_in[e + sz]);
+        if (yh) acc_sgn(tv, pc, p_in[e + sy]);
+        float4 g = ldnt4(grad + e);
+        g.x += s * tv.x; g.y += s * tv.y; g.z += s * tv.z; g.w += s * tv.w;
+        stnt4(grad + e, g);
+      } else {
+        if (xh) tv_local += abs4(pc, pn);
+        if (zh) tv_local += abs4(pc, p_in[e + sz]);
+        if (yh) tv_local += abs4(pc, p_in[e + sy]);
+      }
+      pm = pc;
+      pc = pn;
+    }
+  }
+  if (!GRAD) {
+    tv_local = pp_wave_sum(tv_local);
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) sm[wid] = tv_local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = sm[0] + sm[1] + sm[2] + sm[3];
+      if (t != 0.f) atomicAdd(tv_out, t);
+    }
+  }
+}
+
+// shared launcher (pp_grid_tv_value below, pp_grid_tv_grad in pp_grid.hip); returns false when the shape needs the generic kernels
+bool pp_launch_tv_march(const float* p, int X, int Y, int Z, int C, float scale, const float* g_scalar, float* grad, float* tv_out,
+                        hipStream_t st) {
+  if (C % 4 != 0 || (long long)Y * Z * (C / 4) >= (1ll << 31)) return false;
+  const int q4 = C / 4;
+  int n_chunks = X >= 128 ? 16 : (X >= 8 ? 8 : X);
+  const int chunk_len = (X + n_chunks - 1) / n_chunks;
+  n_chunks = (X + chunk_len - 1) / chunk_len;
+  const int tiles = (int)(((long long)Y * Z * q4 + 255) / 256);
+  const int nv = tiles * n_chunks;
+  if (grad)
+    hipLaunchKernelGGL((k_grid_tv_march<true>), dim3(nv), dim3(256), 0, st, reinterpret_cast<const float4*>(p), X, Y, Z,
+                       q4, n_chunks, chunk_len, nv, scale, g_scalar, reinterpret_cast<float4*>(grad), nullptr);
+  else       // a multiple of n_chunks (itself a multiple of 8 when possible) keeps chunk <-> XCD for every pass of the loop
+    hipLaunchKernelGGL((k_grid_tv_march<false>), dim3(nv < 1024 ? nv : (1024 / n_chunks) * n_chunks), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(p), X, Y, Z, q4, n_chunks, chunk_len, nv, 0.f, nullptr, nullptr, tv_out);
+  return true;
+}
+
 __global__ __launch_bounds__(256) void k_grid_tv_value(const float4* __restrict__ p_in, int X, int Y, int Z, int q4,
                                                        float* __restrict__ tv_out) {
   __shared__ float sm[4];
@@ -206,8 +290,9 @@ extern "C" int pp_grid_tv_value(const float* p, int32_t size_x, int32_t size_y, 
   PP_REQUIRE(p && out, "null pointer");
   const int32_t size[3] = {size_x, size_y, size_z};
   PP_REQUIRE(channels > 0 && channels % 4 == 0, "channels must be a positive multiple of 4");
-  hipLaunchKernelGGL(k_grid_tv_value, dim3(2048), dim3(256), 0, pp_stream(stream), reinterpret_cast<const float4*>(p),
-                     size[0], size[1], size[2], channels / 4, out);
+  if (!pp_launch_tv_march(p, size[0], size[1], size[2], channels, 0.f, nullptr, nullptr, out, pp_stream(stream)))
+    hipLaunchKernelGGL(k_grid_tv_value, dim3(2048), dim3(256), 0, pp_stream(stream), reinterpret_cast<const float4*>(p),
+                       size[0], size[1], size[2], channels / 4, out);
   PP_CHECK_LAUNCH();
   return PP_OK;
 }

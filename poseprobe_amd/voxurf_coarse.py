@@ -134,6 +134,7 @@ class _VoxurfRender(torch.autograd.Function):
         core.forward(ws, k0_cl, sdf_g, flat.view('sdf_ab'), flat.view('rgbnet'), flat.view('warp'), inv_s, pe_w)
         ctx.model, ctx.ws, ctx.flat, ctx.inv_s, ctx.pe_w = model, ws, flat, inv_s, pe_w
         ctx.k0, ctx.sdf_g = k0, sdf_g
+        ctx.set_materialize_grads(False)        # outputs the loss does not use arrive as None in backward, not as zero tensors
         M = ws.M
         depth = ws.t_min / rays_d.detach().norm(dim=-1) + ws.depth_acc
         outs = (ws.rgb_marched, ws.alphainv_last, ws.cum_weights.unsqueeze(-1), ws.weights[:M], ws.alpha[:M], ws.rgb[:M],
@@ -150,26 +151,38 @@ class _VoxurfRender(torch.autograd.Function):
         dev = ws.rays_o.device
 
         def padded(t, width=None):
-            """upstream [M,...] grad -> capacity-sized contiguous buffer"""
-            shape = (cap,) if width is None else (cap, width)
-            b = torch.zeros(shape, device=dev)
+            """upstream [M,...] grad -> capacity-sized contiguous buffer (None stays None: the kernels take NULL for 'no
+            gradient').  Rows past M are never read (every kernel stops at the device-side count), so nothing is zero-filled."""
+            if t is None:
+                return None
+            if M == cap and t.is_contiguous() and t.dtype == torch.float32:
+                return t
+            b = torch.empty((cap,) if width is None else (cap, width), device=dev)
             b[:M] = t.reshape(M, -1) if width else t.reshape(M)
             return b
 
-        ws.g_rgbm.copy_(g_rgbm)
-        ws.g_last.copy_(g_last)
-        ws.g_cw.copy_(g_cw.reshape(-1))
-        g_depth = g_depth.contiguous().float()
+        ws.g_rgbm.copy_(g_rgbm) if g_rgbm is not None else ws.g_rgbm.zero_()
+        ws.g_last.copy_(g_last) if g_last is not None else ws.g_last.zero_()
+        ws.g_cw.copy_(g_cw.reshape(-1)) if g_cw is not None else ws.g_cw.zero_()
+        # `depth` = t_min / |d| + sum w step and `_n_step` = sum w step share the per-sample path; only `depth` has the ray-level term
+        g_depth = None if g_depth is None else g_depth.contiguous().float()
+        if g_depth is None and g_nstep is None:
+            g_depth_all = None
+        elif g_nstep is None:
+            g_depth_all = g_depth
+        else:
+            g_depth_all = g_nstep.contiguous().float() if g_depth is None else g_depth + g_nstep.contiguous().float()
         gg = padded(g_grad, 3)
 
         def add_gradient(w):
-            w.g_gradient.add_(gg)
+            if gg is not None:
+                w.g_gradient[:M].add_(gg[:M])
 
         k0_grad = torch.zeros_like(ctx.k0, memory_format=torch.channels_last_3d)
         core.backward(ws, channels_last_view(ctx.k0), ctx.sdf_g, flat.view('sdf_ab'), flat.view('rgbnet'), flat.view('warp'),
                       ctx.inv_s, ctx.pe_w, channels_last_view(k0_grad), flat.view('sdf_ab', 'grad'),
                       flat.view('rgbnet', 'grad'), flat.view('warp', 'grad'),
-                      g_depth=(g_depth + g_nstep.contiguous().float()), g_weights=padded(g_w),
+                      g_depth=g_depth_all, g_weights=padded(g_w),
                       g_gradient_ext=add_gradient, g_sdf_deform=padded(g_sdfd), g_grad_deform=padded(g_gdef, 9),
                       g_correction=padded(g_corr), g_alpha_ext=padded(g_alpha), g_rgb_ext=padded(g_rgb, 3))
         go, gd, gv = (torch.empty_like(ws.rays_o) for _ in range(3))
