@@ -552,7 +552,12 @@ class TrainEngine:
     # {param index: {'step', 'exp_avg', 'exp_avg_sq'}} + 'param_groups' [{'name', 'lr', 'params': [indices], ...}], one group
     # per `lrate_<name>` key, parameters in `module.parameters()` order (warp_network starts with its gradient-less
     # `progress`, which never gets a state entry).
-    GROUPS = ('sdf_alpha', 'sdf_beta', 'k0', 'rgbnet', 'warp_network')
+    # Group order = the order of the `lrate_<name>` keys of the MERGED training config (lib/utils.py:320-341 walks cfg_train.keys()):
+    # configs/default_fine_s.py contributes lrate_k0, lrate_rgbnet (coarse_train :34-35) and lrate_sdf (surf_train :77) first, the keys
+    # configs/dtu_e2e/scan1.py:87-103 adds (lrate_sdf_alpha, lrate_sdf_beta, ..., lrate_warp_network) follow in its own order (mmengine
+    # merges a child into its base: existing keys keep their place, new ones are appended).  `sdf` (lrate_sdf = 0.1 > 0) IS a group: its
+    # one parameter, the frozen template, never receives a gradient, so it holds a parameter index but no state entry.
+    GROUPS = ('k0', 'rgbnet', 'sdf', 'sdf_alpha', 'sdf_beta', 'warp_network')
 
     def _group_tensors(self, which):
         """{group name: list of tensors in the reference's parameter order and logical shapes} for 'm' or 'v'."""
@@ -562,15 +567,24 @@ class TrainEngine:
         rg = [t for Wb in unpack_rgbnet(P.view('rgbnet', which)) for t in Wb]
         wp = [t for Wb in unpack_warp(P.view('warp', which)) for t in Wb]
         return {'sdf_alpha': [ab[0:1]], 'sdf_beta': [ab[1:2]], 'k0': [self.k0_reference_layout(k0)], 'rgbnet': rg,
+                'sdf': [None],                                     # None = a parameter without optimiser state (frozen template)
                 'warp_network': [None] + wp}                       # None = warp_network.progress (no state)
 
-    def optimizer_state_dict(self):
+    def group_order(self, cfg_train=None):
+        """Optimiser group names in the order the reference builds them for `cfg_train` (any mapping whose keys include the
+        `lrate_<name>` entries; None = the merged scan1 configuration).  Groups whose rate is not positive are frozen, not grouped."""
+        if cfg_train is None:
+            return list(self.GROUPS)
+        known = set(self.GROUPS)
+        return [k[6:] for k in cfg_train.keys() if k.startswith('lrate_') and k[6:] in known and float(cfg_train[k]) > 0]
+
+    def optimizer_state_dict(self, cfg_train=None):
         c = lambda t: t.detach().clone().cpu().contiguous()
         m, v = self._group_tensors('m'), self._group_tensors('v')
         lr = {'sdf_alpha': self.lr['sdf_ab'], 'sdf_beta': self.lr['sdf_ab'], 'k0': self.lr['k0'], 'rgbnet': self.lr['rgbnet'],
-              'warp_network': self.lr['warp']}
+              'warp_network': self.lr['warp'], 'sdf': self.lr['k0']}       # lrate_sdf = lrate_k0 = 0.1 in scan1.py, same decay
         state, groups, idx = {}, [], 0
-        for name in self.GROUPS:
+        for name in self.group_order(cfg_train):
             ids = []
             for tm, tv in zip(m[name], v[name]):
                 if tm is not None and self.n_step > 0:
@@ -611,7 +625,8 @@ class TrainEngine:
                     tv.copy_(d(st['exp_avg_sq']).reshape(tv.shape))
                     steps.append(int(st['step']))
                 key = {'sdf_alpha': 'sdf_ab', 'sdf_beta': 'sdf_ab', 'warp_network': 'warp'}.get(name, name)
-                self.lr[key] = float(grp['lr'])
+                if key in self.lr:                                 # 'sdf': the frozen template has a group but no rate of ours
+                    self.lr[key] = float(grp['lr'])
             if pose_sd is not None and pose_sd.get('state'):
                 st = pose_sd['state'].get(0, pose_sd['state'].get('0'))
                 self.se3_m.copy_(d(st['exp_avg']))
@@ -660,7 +675,7 @@ class TrainEngine:
                 'i_train': list(range(self.V)), 'HW': [[int(self.H), int(self.W)]] * self.V, 'camera_noise': 0.0,
                 'range_shape': rs, 'rect_size': rs}
 
-    def save_checkpoint(self, path, global_step):
+    def save_checkpoint(self, path, global_step, cfg_train=None):
         """The reference's `last_ckpt.tar` (lib/recon_scene.py:779-791): `global_step`, `current_pose`, `model_kwargs`,
         `MaskCache_kwargs`, `model_state_dict`, `optimizer_state_dict`, `optimizer_pose_state_dict` - the optimiser entries in
         torch-Adam layout - plus this engine's pose parametrisation (`se3_refine`, `w2c_init`) and schedule state."""
@@ -671,7 +686,7 @@ class TrainEngine:
                     'model_kwargs': self.model_kwargs(),
                     'MaskCache_kwargs': {'xyz_min': [float(x) for x in cfg.xyz_min], 'xyz_max': [float(x) for x in cfg.xyz_max],
                                          'act_shift': float(np.log(1 / (1 - 1e-2) - 1)), 'voxel_size_ratio': 1.0, 'nearest': False},
-                    'model_state_dict': self.model_state_dict(), 'optimizer_state_dict': self.optimizer_state_dict(),
+                    'model_state_dict': self.model_state_dict(), 'optimizer_state_dict': self.optimizer_state_dict(cfg_train),
                     'optimizer_pose_state_dict': self.pose_optimizer_state_dict(),
                     'se3_refine': c(self.se3), 'w2c_init': c(self.w2c_init),
                     'engine': {'format': 'poseprobe_amd.TrainEngine/2', 'n_step': self.n_step, 'lr': dict(self.lr),

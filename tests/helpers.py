@@ -155,3 +155,50 @@ def check_against_ref96(d, get, tol_pix=dict(rtol=1e-4, atol=1e-5), tol_grad=dic
     assert abs(int(get('k0g.n_touched')) - int(d['k0g.n_touched'])) <= 1e-3 * int(d['k0g.n_touched']), 'number of voxels with a colour-grid gradient'
     assert_close(np.float64(get('k0g.abs_sum')), d['k0g.abs_sum'], rtol=1e-4, name='sum |k0 grad|')
     assert_close(np.float64(get('k0g.sum')), d['k0g.sum'], rtol=1e-3, atol=1e-5 * float(d['k0g.abs_sum']), name='sum k0 grad')
+
+
+# ---------------------------------------------------------------------------------------------------- trajectories
+LR_OF = {'k0': 1e-1, 'se3': 1e-3, 'sdf_ab': 1e-2}         # configs/dtu_e2e/scan1.py:87-103; every MLP tensor: 1e-3
+
+
+def engine_vs_oracle_tensors(eng, st, P):
+    """{name: (engine value, oracle value)} of every trained tensor (numpy float64), reference layouts."""
+    from poseprobe_amd.engine import unpack_rgbnet, unpack_warp
+    c = lambda t: t.detach().cpu().double().numpy()
+    out = {'k0': (c(eng.k0_reference_layout()), c(P['k0'])), 'se3': (c(eng.se3), c(st.se3)),
+           'sdf_ab': (c(eng.flat.view('sdf_ab')), np.concatenate([c(P['sdf_alpha']), c(P['sdf_beta'])]))}
+    for li, (Wt, b) in enumerate(unpack_rgbnet(eng.flat.view('rgbnet'))):
+        out[f'rgbnet{li}.W'], out[f'rgbnet{li}.b'] = (c(Wt), c(P['rgbnet'][li][0])), (c(b), c(P['rgbnet'][li][1]))
+    for li, (Wt, b) in enumerate(unpack_warp(eng.flat.view('warp'))):
+        out[f'warp{li}.W'], out[f'warp{li}.b'] = (c(Wt), c(P['warp'][li][0])), (c(b), c(P['warp'][li][1]))
+    return out
+
+
+def put_engine_at_oracle_state(eng, st):
+    lr = {g['name']: g['lr'] for g in st.groups}
+    eng.load_training_state({g['name']: (g['p'], g['m'], g['v']) for g in st.groups}, st.se3, st.pose_m, st.pose_v, st.n_step,
+                            {'k0': lr['k0'], 'rgbnet': lr['rgbnet.0.weight'], 'warp': lr['warp.0.weight'], 'sdf_ab': lr['sdf_alpha']},
+                            st.lr_pose)
+
+
+def assert_trajectory_close(now, start, n_steps, rtol, crossed=None, what='', coupled=False):
+    """`now` / `start`: engine_vs_oracle_tensors() after / before `n_steps` optimiser steps.  Every entry of every tensor must
+    satisfy  |engine - oracle| <= rtol * |oracle's movement| + 1e-2 * lr  (1e-4 * lr for the colour grid, whose entries move by
+    whole lr-sized steps) - EXCEPT the explicitly identified sign-flip set: Adam's update lr * m / (sqrt(v) + eps) is sign-like,
+    so an entry whose gradient passes through zero (relative to its own history: `crossed[name]` = min_t |g_t| / max_t |g_t|
+    < 1e-2, recorded from the ORACLE's gradients) may take a different +-lr step in two fp32 implementations.  Such entries are
+    counted: at most 5e-4 of a tensor (a handful of a 128 x 128 matrix), each within 2 * lr * n_steps.  Nothing else is excused - except, with coupled=True (long
+    free-running horizons), entries COUPLED to a flipped one: a colour-grid voxel whose neighbour took the other +-0.1 step sees a
+    different total-variation sign sum, a sample through it feeds different colours to the MLPs; those cannot be told from the
+    oracle's own gradient history, so there the count (<= 5e-4) and the magnitude bound alone apply."""
+    for name, (a, b) in now.items():
+        lr = LR_OF.get(name, 1e-3)
+        move = np.abs(b - start[name][1])
+        tol = rtol * move + (1e-4 if name == 'k0' else 1e-2) * lr
+        bad = np.abs(a - b) > tol
+        if not bad.any():
+            continue
+        assert crossed is not None and name in crossed, f'{what}{name}: {bad.sum()} entries beyond rtol {rtol} of the movement (max dev {np.abs(a - b).max():.2e})'
+        assert bad.mean() <= 5e-4, f'{what}{name}: {bad.sum()}/{bad.size} entries deviate'
+        assert coupled or (crossed[name][bad] < 1e-2).all(), f'{what}{name}: a deviating entry never had a near-zero gradient'
+        assert np.abs(a - b)[bad].max() <= 2 * lr * n_steps, f'{what}{name}: outlier beyond 2 lr per step'

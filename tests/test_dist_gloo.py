@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size-2 `gloo` rehearsal of the ray-sharded data-parallel step (poseprobe_amd.dist):
+"""N>1 path on CPU: world_size-2 and world_size-4 `gloo` rehearsal of the ray-sharded data-parallel step (poseprobe_amd.dist):
 reduce-scatter of the dense grid gradient along X, ZeRO-1 sharded TV+Adam, all-gather of the updated slabs and the
 single small all-reduce bucket.  The optimiser arithmetic here is the ORACLE's (no GPU in this container); what is
 under test is the sharding/collective choreography that bench.py --gpus N runs with RCCL."""
@@ -72,9 +72,8 @@ def _worker(rank, world, port, X, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('X', [8, 6])
-def test_sharded_step_equals_single_process(X):
-    world = 2
+@pytest.mark.parametrize('X,world', [(8, 2), (6, 2), (8, 4)])
+def test_sharded_step_equals_single_process(X, world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -85,6 +84,12 @@ def test_sharded_step_equals_single_process(X):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _sample_count(rank, world):
+    """Samples a rank contributes to the exchange: ragged, and at world size 4 rank 2 has NO sample at all (all its rays miss the
+    box) - its buffer still travels (row 0 carries the count 0) and contributes nothing to the replay."""
+    return [20, 27, 0, 41][rank] if world == 4 else 20 + 7 * rank
 
 
 def _worker_samples(rank, world, port, q):
@@ -98,7 +103,7 @@ def _worker_samples(rank, world, port, q):
     assert not ctx.local_scatter
     cap, G, C = 64, 6, 12
     g = torch.Generator().manual_seed(11 + rank)
-    M = 20 + 7 * rank                                            # ragged: a different sample count per rank
+    M = _sample_count(rank, world)                               # ragged: a different sample count per rank, one rank EMPTY at W = 4
     packed = torch.zeros(cap, 16)
     packed[:M, :C] = torch.randn(M, C, generator=g)
     packed[:M, 12:15] = torch.rand(M, 3, generator=g)            # positions in [0,1)^3
@@ -124,7 +129,7 @@ def _worker_samples(rank, world, port, q):
     dist.all_gather(gs, mine)
     ok = torch.equal(mine, ref) and all(torch.equal(gs[0], x) for x in gs)
     counts = [int(out[r, 0, 15:16].view(torch.int32)[0]) for r in range(world)]
-    ok = ok and counts == [20 + 7 * r for r in range(world)]
+    ok = ok and counts == [_sample_count(r, world) for r in range(world)]
     # periodic resync primitive
     t = torch.full((4,), float(rank))
     ctx.broadcast_state([t])
@@ -156,8 +161,8 @@ def _worker_samples(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sample_exchange_equals_single_process():
-    world = 2
+@pytest.mark.parametrize('world', [2, 4])
+def test_sample_exchange_equals_single_process(world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -168,6 +173,11 @@ def test_sample_exchange_equals_single_process():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_default_exchange_mode_per_world_size():
+    from poseprobe_amd.dist import default_mode
+    assert [default_mode(w) for w in (1, 2, 4, 8, 16)] == ['samples'] * 4 + ['zero1']
 
 
 def test_slab_bounds_cover_grid():

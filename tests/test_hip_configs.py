@@ -34,11 +34,11 @@ CONFIGS = {
 H = W = 400
 GS = 10
 
-def _engine(r):
+def _engine(r, **kw):
     """A fresh engine holding configuration r's initial parameters."""
     from poseprobe_amd.engine import TrainEngine
     c, views, P = r['c'], r['views'], r['P']
-    eng = TrainEngine(r['cfg'], c['V'], H, W, c['N'], pose_iters=3000, fix_first=c['fix_first'])
+    eng = TrainEngine(r['cfg'], c['V'], H, W, c['N'], pose_iters=3000, fix_first=c['fix_first'], **kw)
     eng.set_views(views['images'], views['masks'], views['Ks'], views['w2c'])
     eng.load_reference_params(P['k0'], P['sdf'], P['sdf_alpha'], P['sdf_beta'], P['rgbnet'], P['warp'],
                               se3=torch.tensor(r['se3_np']))
@@ -212,23 +212,25 @@ def test_c1_toy_trajectory_matches_the_oracle_trainer(run):
     from poseprobe_amd import synthetic as syn
     from poseprobe_amd.engine import unpack_rgbnet
     import copy
+    from tests.helpers import assert_trajectory_close, engine_vs_oracle_tensors
     r = run
-    eng, scene, views = _engine(r), r['scene'], r['views']
+    scene, views = r['scene'], r['views']
+    eng = _engine(r, deterministic_scatter=True)
     P = copy.deepcopy({k: ([(a.detach(), b.detach()) for a, b in v] if isinstance(v, list) else v.detach()) for k, v in r['P'].items()})
     st = O.TrainState(P, scene, torch.tensor(views['w2c']), torch.tensor(views['Ks']), torch.tensor(views['images']),
                       torch.tensor(views['masks']), se3_refine=torch.tensor(r['se3_np']), pose_iters=3000, fix_first=False)
     eng.zero_grads()
+    start = engine_vs_oracle_tensors(eng, st, P)
     for s in range(3):
         idx, jit = syn.step_randomness(H * W, 1024, seed=70 + s)
         st.step(torch.tensor(idx), torch.tensor(jit), GS + s)
         eng.train_step(torch.tensor(idx, dtype=torch.int32, device='cuda'), torch.tensor(jit, device='cuda'), GS + s)
     torch.cuda.synchronize()
-    c = lambda t: t.detach().cpu().numpy()
-    dev = np.abs(c(eng.k0_reference_layout()) - c(P['k0']))
-    assert dev.max() <= 0.02 and (dev > 1e-4).mean() < 0.02, (dev.max(), (dev > 1e-4).mean())
-    assert_close(c(eng.se3), c(st.se3), rtol=0, atol=2e-4, name='se3 after 3 steps')
-    W1 = unpack_rgbnet(eng.flat.view('rgbnet'))[1][0]
-    assert (np.abs(c(W1) - c(P['rgbnet'][1][0])) > 1e-4).mean() < 0.02
+    # deterministic colour-grid scatter: every entry within 1e-3 of its movement (+ 1e-2 lr; grid 1e-4 lr), at most 5e-4 of a
+    # tensor excused and bounded by 2 lr per step (tests/helpers.py assert_trajectory_close) - was: atol 0.02 / 2 % of entries
+    now = engine_vs_oracle_tensors(eng, st, P)
+    assert_trajectory_close(now, start, 3, rtol=1e-3, crossed={k: np.zeros_like(v[0]) for k, v in now.items()}, what='c1, 3 steps: ',
+                            coupled=True)
 
 
 @pytest.mark.parametrize('run', ['c4_synthetic_256_6view'], indirect=True)

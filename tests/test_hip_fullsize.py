@@ -153,3 +153,68 @@ def test_optimizer_identities_at_full_grid(engine):
     for xb, xe in ((0, 20), (20, 100), (100, X)):
         ops.grid_tv_adam_step(p_in, pb, gb, mb, vb, (X, Y, Z), cfg.k0_dim, xb, xe, 1e-6, 1.0, 0.1, 0.9, 0.99, 1e-8, 3, None)
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+
+
+@pytest.mark.parametrize('mode', ['samples', 'zero1'])
+def test_dist_choreographies_at_the_multi_gpu_workload_on_one_rank(mode):
+    """BASELINE config 3's per-rank workload (160^3 grid, 1024 rays of 3 x 400 x 400 views, ~55 k samples) through DistContext
+    and RCCL with world_size 1, so that the pack / exchange / replay kernels ("samples": pp_k0_pack_samples -> all-gather of
+    the exact row count -> pp_k0_scatter_packed_sorted) and the dense path ("zero1": reduce-scatter -> slab TV + Adam ->
+    all-gather) see REAL sizes (VERDICT r02 #7a; tests/test_hip_step.py runs them at 8^3).  With the deterministic scatter the
+    colour grid after the first step must equal the plain engine's BIT FOR BIT (everything upstream of the scatter is free of
+    atomics; the replay adds in (rank, sample, corner) order exactly like the plain sorted scatter); the second step differs in
+    the last bits only through the MLP weight-gradient atomics."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from poseprobe_amd import synthetic as syn
+    from poseprobe_amd.dist import DistContext
+    from poseprobe_amd.engine import SceneConfig, TrainEngine
+    from poseprobe_amd.params_init import reference_like_params
+    if not dist.is_initialized():
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    G, H, W, V, N = 160, 400, 400, 3, 1024
+    cfg = SceneConfig(syn.XYZ_MIN, syn.XYZ_MAX, G ** 3, out_range=float(syn.range_shape().max()))
+    views = syn.make_views(V, H, W)
+    P = reference_like_params(cfg, 3)
+
+    def make(dctx):
+        e = TrainEngine(cfg, V, H, W, N, pose_iters=3000, dist_ctx=dctx, deterministic_scatter=True)
+        e.set_views(views['images'], views['masks'], views['Ks'], views['w2c'])
+        e.load_reference_params(P['k0'], P['sdf'], P['sdf_alpha'], P['sdf_beta'], P['rgbnet'], P['warp'],
+                                se3=torch.tensor(syn.se3_perturbation(V)))
+        e.zero_grads()
+        return e
+
+    plain = make(None)
+    dctx = DistContext(mode=mode, resync_every=2)
+    sharded = make(dctx)
+    after_first = {}
+    for eng in (plain, sharded):
+        for s in range(2):
+            idx, jit = syn.step_randomness(V * H * W, N, seed=40 + s)
+            eng.train_step(torch.tensor(idx, dtype=torch.int32, device='cuda'), torch.tensor(jit, device='cuda'), 10 + s)
+            if s == 0:
+                torch.cuda.synchronize()
+                after_first[id(eng)] = (eng.k0_cl.clone(), int(eng.ws.count.item()))
+    torch.cuda.synchronize()
+    k_plain, M_plain = after_first[id(plain)]
+    k_shard, M_shard = after_first[id(sharded)]
+    assert M_plain == M_shard and 30000 < M_plain < 100000
+    if mode == 'samples':          # the replay adds in (rank, sample, corner) order, exactly like the plain engine's sorted scatter
+        assert torch.equal(k_plain, k_shard), 'colour grid after the first "samples" step differs from the plain engine'
+    else:                          # zero1 reduces the DENSE gradient, which the colour-feature backward fills with float atomics
+        d1 = (k_plain - k_shard).abs()
+        assert float(d1.max()) <= 0.2 and float((d1 > 1e-4).float().mean()) < 1e-4, (float(d1.max()), float((d1 > 1e-4).float().mean()))
+    if mode == 'samples':
+        M_last = int(sharded.ws.count.item())                      # rows are sized per step from that step's exact count
+        assert dctx.rows is not None and dctx.rows % 1024 == 0 and 0 <= dctx.rows - M_last < 1024, (dctx.rows, M_last)
+    c = lambda t: t.detach().cpu().numpy()
+    a, b = c(sharded.k0_cl), c(plain.k0_cl)
+    assert (np.abs(a - b) > 1e-4).mean() < 1e-3, (np.abs(a - b) > 1e-4).mean()
+    assert np.abs(c(sharded.se3) - c(plain.se3)).max() < 2e-4
+    assert (np.abs(c(sharded.flat.data) - c(plain.flat.data)) > 1e-4).mean() < 0.02
+    del plain, sharded
+    torch.cuda.empty_cache()

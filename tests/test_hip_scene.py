@@ -644,3 +644,68 @@ def test_band_weight_kernel_equals_the_torch_expression():
             k = torch.arange(L, dtype=torch.float32, device='cuda')
             ref.append((1 - (alpha - k).clamp_(min=0, max=1).mul_(math.pi).cos_()) / 2)
         assert_close(out, torch.cat(ref), rtol=0, atol=1.2e-7, name=f'bands at {p}')
+
+
+@pytest.mark.parametrize('nerf_split', [1, 0])
+def test_scene_kernels_stay_inside_their_buffers(nerf_split):
+    """Fence around the scene GEMM chain ("the memory-access fault of 4 Oct"): pp_nerf_fwd / pp_nerf_bwd
+    at 1023 x 128 (the reference batch: 1023 row tiles of 128, every persistent work-group walks four tiles), 1 x 2 (less than
+    one tile) and 37 x 50 (1850 rows: a ragged last tile, more tiles than nothing else exercises at this size) with every
+    caller-owned buffer the kernels WRITE - the activation block (whose tail holds the ReLU mask planes and the split weight
+    images), the backward scratch, both sample outputs, the parameter-gradient block, both ray gradients - embedded in a
+    sentinel-filled arena: 64 KB of sentinels in front of and behind each must survive both passes, in both arithmetic modes.
+    Run once per build, as every other test (no repetition: an out-of-bounds access is deterministic in the indexing)."""
+    from poseprobe_amd import bg_nerf, ops
+    dev = 'cuda'
+    PAD = 16384                                                     # floats = 64 KB
+    SENT = 0x7FC0DEAD                                               # a quiet-NaN payload no kernel produces
+
+    def fenced(n, fill=None):
+        arena = torch.empty(n + 2 * PAD, dtype=torch.int32, device=dev).fill_(SENT).view(torch.float32)
+        body = arena[PAD:PAD + n]
+        if fill is not None:
+            body.copy_(fill) if isinstance(fill, torch.Tensor) else body.fill_(fill)
+        return arena, body
+
+    def intact(arena, n, what):
+        a = arena.view(torch.int32)
+        assert bool((a[:PAD] == SENT).all()), f'{what}: sentinels IN FRONT of the buffer were overwritten'
+        assert bool((a[PAD + n:] == SENT).all()), f'{what}: sentinels BEHIND the buffer were overwritten'
+
+    opt = bg_nerf.default_options(sample_intvs=128)
+    torch.manual_seed(3)
+    net = bg_nerf.NeRF(opt, device=dev, options={'nerf_split': nerf_split, 'nerf_split_tn': nerf_split})
+    net.progress.data.fill_(0.7)
+    g = torch.Generator().manual_seed(21)
+    for R, S in ((1023, 128), (1, 2), (37, 50)):
+        M = R * S
+        center = (torch.randn(R, 3, generator=g) * 0.3).to(dev)
+        ray = torch.randn(R, 3, generator=g).to(dev)
+        depth = ((torch.rand(R, S, generator=g) + torch.arange(S)) / S * 2.0 + 0.4).to(dev).contiguous()
+        count = torch.tensor([M], dtype=torch.int32, device=dev)
+        n_acts, n_scr = ops.nerf_workspace(M, R)
+        acts_a, acts = fenced(n_acts)
+        scr_a, scr = fenced(n_scr, 0.0)
+        rgb_a, rgb_s = fenced(M * 3)
+        den_a, dens = fenced(M)
+        pg_a, pgrad = fenced(net.flat.numel(), 0.0)
+        gc_a, g_center = fenced(R * 3)
+        gr_a, g_ray = fenced(R * 3)
+        ops.nerf_fwd(net.flat, center, ray, depth, net.band_weights(), count, R, S, acts, rgb_s.view(M, 3), dens, net.ctx)
+        torch.cuda.synchronize()
+        for arena, n, what in ((acts_a, n_acts, 'acts'), (rgb_a, M * 3, 'rgb_samples'), (den_a, M, 'density_samples')):
+            intact(arena, n, f'{R}x{S} forward, {what}')
+        assert bool(torch.isfinite(rgb_s).all()) and bool(torch.isfinite(dens).all())
+        g_rgb = torch.randn(M, 3, generator=g).to(dev)
+        g_den = torch.randn(M, generator=g).to(dev)
+        ops.nerf_bwd(net.flat, ray, depth, count, R, S, acts, rgb_s.view(M, 3), g_rgb, g_den, scr, pgrad, g_center.view(R, 3),
+                     g_ray.view(R, 3), net.ctx)
+        torch.cuda.synchronize()
+        for arena, n, what in ((acts_a, n_acts, 'acts'), (scr_a, n_scr, 'scratch'), (pg_a, net.flat.numel(), 'params_grad'),
+                               (gc_a, R * 3, 'g_center'), (gr_a, R * 3, 'g_ray'), (rgb_a, M * 3, 'rgb_samples'),
+                               (den_a, M, 'density_samples')):
+            intact(arena, n, f'{R}x{S} backward, {what}')
+        assert bool(torch.isfinite(pgrad).all()) and bool(torch.isfinite(g_center).all()) and bool(torch.isfinite(g_ray).all())
+        assert float(pgrad.abs().max()) > 0
+        del acts_a, scr_a, acts, scr
+        torch.cuda.empty_cache()

@@ -83,10 +83,12 @@ def test_fused_step_matches_reference(tag):
 
 
 def test_trajectory_3_steps_matches_oracle():
-    """3 optimiser steps (Adam on grid + MLPs + pose with lr schedules) against the oracle trainer."""
+    """3 optimiser steps (Adam on grid + MLPs + pose with lr schedules) against the oracle trainer on the smallest fixture, with
+    the DEFAULT (atomic) scatter: everything within 1e-3 of its movement except a counted, bounded set (tests/helpers.py
+    assert_trajectory_close; the deterministic-scatter variants below pin the rest)."""
     from oracle import voxurf_oracle as O
     from poseprobe_amd import synthetic as syn
-    from tests.helpers import scene_for
+    from tests.helpers import assert_trajectory_close, engine_vs_oracle_tensors, scene_for
     d = load('forward_g8_s10.npz')
     eng, cfg = build_engine(d, pose_iters=1000)
     P = params_from_npz(d)
@@ -94,23 +96,15 @@ def test_trajectory_3_steps_matches_oracle():
                       torch.tensor(d['masks']), se3_refine=torch.tensor(d['se3']), pose_iters=1000)
     eng.zero_grads()
     V, H, W = d['images'].shape[:3]
+    start = engine_vs_oracle_tensors(eng, st, P)
     for s in range(3):
         idx, jit = syn.step_randomness(V * H * W, int(d['n_rand']), seed=40 + s)
         st.step(torch.tensor(idx), torch.tensor(jit), 10 + s)
         eng.train_step(torch.tensor(idx, dtype=torch.int32, device='cuda'), torch.tensor(jit, device='cuda'), 10 + s)
     torch.cuda.synchronize()
-    c = lambda t: t.detach().cpu().numpy()
-    # Adam's first steps move every parameter by ~lr regardless of gradient magnitude (sign-like), so elements whose
-    # gradient is at rounding-noise level may legitimately differ; compare with an absolute budget of a few % of lr.
-    assert_close(c(eng.k0_reference_layout()), c(P['k0']), rtol=0, atol=0.02, name='k0 after 3 steps')
-    frac = (np.abs(c(eng.k0_reference_layout()) - c(P['k0'])) > 1e-4).mean()
-    assert frac < 0.02, f'{frac:.3%} of k0 entries deviate by more than 1e-4'
-    assert_close(c(eng.se3), c(st.se3), rtol=0, atol=2e-4, name='se3 after 3 steps')
-    rg = eng.flat.view('rgbnet')
-    from poseprobe_amd.engine import unpack_rgbnet
-    W1 = unpack_rgbnet(rg)[1][0]
-    dev = np.abs(c(W1) - c(P['rgbnet'][1][0]))
-    assert (dev > 1e-4).mean() < 0.02, 'rgbnet layer-1 weights deviate after 3 steps'
+    now = engine_vs_oracle_tensors(eng, st, P)
+    assert_trajectory_close(now, start, 3, rtol=1e-3, crossed={k: np.zeros_like(v[0]) for k, v in now.items()}, what='3 steps: ',
+                            coupled=True)
 
 
 @pytest.mark.parametrize('mode', ['samples', 'zero1'])
@@ -192,12 +186,14 @@ def test_checkpoint_resume_reproduces_the_trajectory(tmp_path):
     assert torch.equal(m2.rgbnet[0].weight.detach().cpu(), ck['model_state_dict']['rgbnet.0.weight'])
     # ... and its optimiser entries load into the reference's optimiser classes (torch-Adam layout, lib/utils.py:316-362)
     from poseprobe_amd.config import ConfigDict
-    cfg_train = ConfigDict(lrate_decay=10, lrate_sdf_alpha=1e-2, lrate_sdf_beta=1e-2, lrate_k0=1e-1, lrate_rgbnet=1e-3,
+    # lrate_* keys in the order of the merged scan1 training config (configs/default_fine_s.py:34-35, :77, then
+    # configs/dtu_e2e/scan1.py:87-103); lrate_sdf = 0.1 makes the frozen template a group of its own
+    cfg_train = ConfigDict(lrate_k0=1e-1, lrate_rgbnet=1e-3, lrate_decay=10, lrate_sdf=0.1, lrate_sdf_alpha=1e-2, lrate_sdf_beta=1e-2,
                            lrate_warp_network=1e-3, lr_pose=1e-3, lr_pose_end=1e-4, sched_pose='ExponentialLR')
     opt = utils.create_optimizer_or_freeze_model(m2, cfg_train, global_step=0)
     assert [g['name'] for g in opt.param_groups] == [g['name'] for g in ck['optimizer_state_dict']['param_groups']]
     opt.load_state_dict(ck['optimizer_state_dict'])
-    k0_state = opt.state[opt.param_groups[2]['params'][0]]
+    k0_state = opt.state[opt.param_groups[0]['params'][0]]
     assert k0_state['step'] == 2 and tuple(k0_state['exp_avg'].shape) == tuple(m2.k0.grid.shape)
     assert_close(k0_state['exp_avg'].permute(0, 2, 3, 4, 1)[0], n(b.k0_m), rtol=0, atol=0, name='k0 exp_avg through torch-Adam')
 
@@ -236,7 +232,10 @@ def test_reference_layout_optimizer_state_round_trips_through_a_torch_optimizer(
     assert_close(n(eng.flat.view('sdf_ab', 'm')), np.concatenate([n(st('sdf_alpha', 0)['exp_avg']), n(st('sdf_beta', 0)['exp_avg'])]),
                  rtol=0, atol=0, name='alpha / beta exp_avg')
     # and back: the engine's own export is accepted by the torch optimiser and equals what went in
-    back = eng.optimizer_state_dict()
+    # (the export follows the group order of the training config it is given: this hand-made one has no lrate_sdf and its own
+    # key order, the default is the merged scan1 order - test_optimizer_state_dict_loads_into_the_reference_style_optimizer)
+    back = eng.optimizer_state_dict(cfg_train)
+    assert [g['name'] for g in back['param_groups']] == [g['name'] for g in sd['param_groups']]
     opt2 = utils.create_optimizer_or_freeze_model(make_model(d), cfg_train, global_step=0)
     opt2.load_state_dict(back)
     for i, s_in in sd['state'].items():
@@ -413,3 +412,132 @@ def test_two_engines_with_different_arithmetic_coexist():
     assert not torch.equal(a.ws.rgb[:Ma], b.ws.rgb[:Ma])          # two arithmetics ...
     assert_close(a.ws.rgb_marched, b.ws.rgb_marched.cpu(), rtol=1e-4, atol=1e-5, name='split vs fp32 pixels')     # ... one result
     assert _lib.default_context().options() == before
+
+
+@pytest.mark.parametrize('tag', ['g24_s10', 'g24_s7000'])
+def test_every_optimiser_step_along_a_trajectory_matches_the_oracle(tag):
+    """Teacher-forced: at each of 10 consecutive steps the engine is put at the ORACLE trainer's
+    state (parameters, both Adam moments, poses, learning rates, step count: engine.load_training_state), takes its own step on
+    the same rays and jitter, and every parameter of every tensor must land where the oracle's step lands: within 1e-4 of the
+    entry's movement + 1e-2 lr (colour grid 1e-4 lr).  No blanket allowance: a wrong bias correction, beta, eps placement,
+    per-group lr or decay exponent moves every entry by more than that (lib/utils.py:82-198, lib/recon_scene.py:742-747).
+    The only entries excused are those whose gradient at this step is below the GRADIENT parity budget itself (|g| < 5e-5 of
+    the tensor's largest entry, the `scaled` term of the gradient comparisons above): there lr * g / (|g| + eps) amplifies an
+    admissible 1e-10 gradient difference by lr / eps = 1e5; they are counted (<= 5e-4 of a tensor) and bounded (2 lr)."""
+    from oracle import voxurf_oracle as O
+    from poseprobe_amd import synthetic as syn
+    from tests.helpers import (assert_trajectory_close, engine_vs_oracle_tensors, put_engine_at_oracle_state, scene_for)
+    d = load(f'forward_{tag}.npz')
+    gs0 = int(d['global_step'])
+    eng, cfg = build_engine(d, pose_iters=1000, deterministic_scatter=True)
+    P = params_from_npz(d)
+    st = O.TrainState(P, scene_for(d['G']), torch.tensor(d['w2c_init']), torch.tensor(d['Ks']), torch.tensor(d['images']),
+                      torch.tensor(d['masks']), se3_refine=torch.tensor(d['se3']), pose_iters=1000)
+    eng.zero_grads()
+    V, H, W = d['images'].shape[:3]
+    for s in range(10):
+        idx, jit = syn.step_randomness(V * H * W, int(d['n_rand']), seed=40 + s)
+        put_engine_at_oracle_state(eng, st)
+        start = engine_vs_oracle_tensors(eng, st, P)
+        for name, (a, b) in start.items():
+            assert np.array_equal(a.astype(np.float32), b.astype(np.float32)), f'{name}: state hand-over is not exact'
+        st.step(torch.tensor(idx), torch.tensor(jit), gs0 + s)
+        eng.train_step(torch.tensor(idx, dtype=torch.int32, device='cuda'), torch.tensor(jit, device='cuda'), gs0 + s)
+        torch.cuda.synchronize()
+        small = {}                        # score < 1e-2  <=>  |g| < 5e-5 max|g|
+        for li in range(4):
+            for w, t in zip(('W', 'b'), P['rgbnet'][li]):
+                small[f'rgbnet{li}.{w}'] = t.grad
+        for li in range(5):
+            for w, t in zip(('W', 'b'), P['warp'][li]):
+                small[f'warp{li}.{w}'] = t.grad
+        small = {k: (g.detach().abs().double() / (g.detach().abs().max().double() + 1e-30) * 200.0).numpy() for k, g in small.items()}
+        assert_trajectory_close(engine_vs_oracle_tensors(eng, st, P), start, 1, rtol=1e-4, crossed=small, what=f'step {s + 1}: ')
+
+
+@pytest.mark.parametrize('n_steps', [3, 10])
+def test_free_running_trajectory_with_deterministic_scatter_matches_the_oracle(n_steps):
+    """Free-running 3- and 10-step trajectories (grid + MLPs + alpha / beta + poses) with the deterministic colour-grid scatter
+    against the oracle trainer at rtol 1e-3 of each entry's movement (+ 1e-2 lr; colour grid 1e-4 lr).  The only entries excused
+    are the explicitly identified sign-flip set - entries whose ORACLE gradient passed through zero relative to its own history
+    (min_t |g_t| / max_t |g_t| < 1e-2), where Adam's sign-like update may take the other +-lr step - and they are counted
+    (<= 5e-4 of a tensor) and bounded (2 lr per step).  Replaces the blanket "2 % of entries / atol 0.02" of round 2."""
+    from oracle import voxurf_oracle as O
+    from poseprobe_amd import synthetic as syn
+    from tests.helpers import assert_trajectory_close, engine_vs_oracle_tensors, scene_for
+    d = load('forward_g24_s10.npz')
+    eng, cfg = build_engine(d, pose_iters=1000, deterministic_scatter=True)
+    P = params_from_npz(d)
+    st = O.TrainState(P, scene_for(d['G']), torch.tensor(d['w2c_init']), torch.tensor(d['Ks']), torch.tensor(d['images']),
+                      torch.tensor(d['masks']), se3_refine=torch.tensor(d['se3']), pose_iters=1000)
+    eng.zero_grads()
+    V, H, W = d['images'].shape[:3]
+    start = engine_vs_oracle_tensors(eng, st, P)
+    gmin, gmax = {}, {}
+    names = {'k0': lambda: P['k0'].grad}
+    for li in range(4):
+        names[f'rgbnet{li}.W'] = (lambda li=li: P['rgbnet'][li][0].grad)
+        names[f'rgbnet{li}.b'] = (lambda li=li: P['rgbnet'][li][1].grad)
+    for li in range(5):
+        names[f'warp{li}.W'] = (lambda li=li: P['warp'][li][0].grad)
+        names[f'warp{li}.b'] = (lambda li=li: P['warp'][li][1].grad)
+    for s in range(n_steps):
+        idx, jit = syn.step_randomness(V * H * W, int(d['n_rand']), seed=40 + s)
+        st.step(torch.tensor(idx), torch.tensor(jit), 10 + s)
+        eng.train_step(torch.tensor(idx, dtype=torch.int32, device='cuda'), torch.tensor(jit, device='cuda'), 10 + s)
+        for name, get in names.items():
+            g = get().detach().abs().double().numpy()
+            gmin[name] = g if name not in gmin else np.minimum(gmin[name], g)
+            gmax[name] = g if name not in gmax else np.maximum(gmax[name], g)
+    torch.cuda.synchronize()
+    crossed = {name: gmin[name] / (gmax[name] + 1e-30) for name in names}
+    assert_trajectory_close(engine_vs_oracle_tensors(eng, st, P), start, n_steps, rtol=1e-3, crossed=crossed, what=f'{n_steps} steps: ',
+                            coupled=n_steps > 3)
+
+
+def test_optimizer_state_dict_loads_into_the_reference_style_optimizer():
+    """the real configs set lrate_sdf = 0.1 (configs/dtu_e2e/scan1.py:87), so the reference's
+    create_optimizer_or_freeze_model (lib/utils.py:316-342) builds SIX groups in the order of the merged config's lrate_* keys -
+    k0, rgbnet, sdf (configs/default_fine_s.py:34-35, :77), then sdf_alpha, sdf_beta, warp_network (scan1.py:89-102) - the
+    frozen template `sdf` holding a parameter index without state.  An engine checkpoint's optimizer_state_dict must load into an
+    optimiser built that way over the drop-in module (torch checks group count and sizes) and put every moment on the right tensor;
+    a config without lrate_sdf gives the five-group layout."""
+    from poseprobe_amd import synthetic as syn, utils
+    from poseprobe_amd.config import ConfigDict
+    d = load('forward_g8_s10.npz')
+    eng, _ = build_engine(d, pose_iters=1000)
+    eng.zero_grads()
+    V, H, W = d['images'].shape[:3]
+    for s in range(2):
+        idx, jit = syn.step_randomness(V * H * W, int(d['n_rand']), seed=80 + s)
+        eng.train_step(torch.tensor(idx, dtype=torch.int32, device='cuda'), torch.tensor(jit, device='cuda'), 10 + s)
+    torch.cuda.synchronize()
+    # the lrate_* keys of the merged scan1 training config, in its key order (other keys omitted)
+    cfg_train = ConfigDict(lrate_density=1e-1, lrate_k0=1e-1, lrate_rgbnet=1e-3, lrate_decay=10, lrate_sdf=0.1, lrate_sdfnet=1e-3,
+                           lrate_sdf_delta=1e-3, lrate_sdf_alpha=1e-2, lrate_sdf_beta=1e-2, lrate_point_deform=2e-5,
+                           lrate_sdf_delta_conv=1e-3, lrate_k_rgbnet=1e-3, lrate_rgb_addnet=1e-3, lrate_warp_network=1e-3)
+    assert eng.group_order(cfg_train) == eng.group_order() == ['k0', 'rgbnet', 'sdf', 'sdf_alpha', 'sdf_beta', 'warp_network']
+    sd = eng.optimizer_state_dict(cfg_train)
+    assert [g['name'] for g in sd['param_groups']] == eng.group_order()
+    assert [len(g['params']) for g in sd['param_groups']] == [1, 8, 1, 1, 1, 11]
+    sdf_id = sd['param_groups'][2]['params'][0]
+    assert sdf_id == 9 and sdf_id not in sd['state']               # k0 (1) + rgbnet (8) come first; no state for the frozen template
+    model = eng.voxurf_view()
+    opt = utils.create_optimizer_or_freeze_model(model, cfg_train, global_step=0)
+    assert [g['name'] for g in opt.param_groups] == eng.group_order()
+    opt.load_state_dict(sd)                                        # raises on a group-count / size mismatch
+    k0_state = opt.state[opt.param_groups[0]['params'][0]]
+    assert int(k0_state['step']) == 2
+    assert torch.equal(k0_state['exp_avg'].cpu(), eng.k0_reference_layout(eng.k0_m).cpu())
+    w_last = opt.param_groups[5]['params'][-2]                      # warp_network ... net.4.0.weight
+    from poseprobe_amd.engine import unpack_warp
+    assert torch.equal(opt.state[w_last]['exp_avg_sq'].cpu(), unpack_warp(eng.flat.view('warp', 'v'))[4][0].cpu())
+    # and back: the engine reads the reference-style optimiser's state (six groups, one of them without state)
+    eng2, _ = build_engine(d, pose_iters=1000)
+    eng2.load_optimizer_state_dict(opt.state_dict())
+    assert eng2.n_step == 2 and torch.equal(eng2.k0_m, eng.k0_m) and torch.equal(eng2.flat.v, eng.flat.v)
+    assert set(eng2.lr) == set(eng.lr)
+    # a training config without lrate_sdf (or with 0): five groups, as round 2 wrote them
+    five = ConfigDict(lrate_k0=1e-1, lrate_rgbnet=1e-3, lrate_sdf=0, lrate_sdf_alpha=1e-2, lrate_sdf_beta=1e-2, lrate_warp_network=1e-3)
+    assert eng.group_order(five) == ['k0', 'rgbnet', 'sdf_alpha', 'sdf_beta', 'warp_network']
+    assert len(eng.optimizer_state_dict(five)['param_groups']) == 5
