@@ -45,7 +45,7 @@ def default_mode(world):
     """The exchange mode a world size runs by default (DESIGN.md 7, table "predicted step time"): from the measured kernel
     times of the 160^3 / 1024-ray step and a 50-60 GB/s usable xGMI link, "samples" (3.6 MB per rank on the wire, replicated
     248-295 us grid pass, W x 17 us replayed scatters) beats "zero1" (2 x 196 MB / W per link, grid pass / W) at every W <= 8:
-    1.13 / 1.18 / 1.27 ms against 3.7 / 2.0 / 1.1-2.9 ms at W = 2 / 4 / 8 - zero1 only comes close at W = 8 and only if RCCL
+    1.13 / 1.18 / 1.26 ms against 4.0 / 2.1-5.7 / 1.2-6.5 ms at W = 2 / 4 / 8 - zero1 only comes close at W = 8 and only if RCCL
     really drives all seven links at once.  Beyond one node (W > 8) the replay grows linearly and the dense pass is 1/W: zero1.
     PP_DIST_MODE overrides; the driver's SCALE run is the measurement that settles it."""
     return 'samples' if world <= 8 else 'zero1'
