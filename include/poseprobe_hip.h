@@ -170,7 +170,7 @@ int pp_geometry_bwd(const pp_scene* sc, const float* sdf_grid, const float* sdf_
  * evaluated from the recomputed forward, their values accumulated into loss_out[2..5] (as pp_loss_samples does) and
  * their gradients folded into the backward without the g_grad_deform / g_correction / g_sdf_deform round trip through
  * HBM.  g_gradient[M,3] = upstream gradient of the normal from the colour features (may be NULL).  Bit-identical to the
- * two-call sequence. */
+ * two-call sequence (except loss_out[7], the weighted total, which only pp_loss_rays / pp_loss_samples maintain). */
 int pp_geometry_bwd_priors(const pp_scene* sc, const float* sdf_grid, const float* sdf_ab, const float* pts,
                            const float* warp_out, const float* viewdirs, const int32_t* ray_id, const int32_t* count,
                            int32_t capacity, float inv_s, const float* g_alpha, const float* g_gradient, float w_eikonal,
@@ -292,7 +292,8 @@ int pp_rgbnet_bwd_weights(const float* feat, const float* acts, const float* scr
  * forward values + gradients w.r.t. the render outputs in one pass.  loss_scale multiplies every gradient
  * (recon_scene.py:648 scales the object loss by 0.1).
  * loss_out[8] (atomic +=, caller zeroes): [0] mse, [1] entropy, [2] eikonal, [3] grad_deform, [4] sdf_correct,
- * [5] sdf_deform, [6] bce mask, [7] unused (unweighted scalars, as loss_scalars in the reference).
+ * [5] sdf_deform, [6] bce mask (unweighted scalars, as loss_scalars in the reference), [7] the WEIGHTED sum of the seven
+ * (each kernel adds its share with its w_* arguments, loss_scale not applied): object_losses' `loss` without the TV term.
  * mask_sum[1] receives the batch's masked-pixel count.  g_rgb_marched is w.r.t. the CLAMPED rgb_marched
  * (pp_march_bwd applies the clamp mask).
  * batch_norm (device float[2], may be NULL): ray-sharded data parallelism.  The reference normalises the masked MSE by
@@ -388,6 +389,11 @@ int pp_sample_bg(const float* rays_o, const float* rays_d, const float* t_max, f
                  int32_t n_samples, float* pts, void* stream);
 int pp_adam_upd(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* perlr, int32_t n,
                 int32_t step, float beta1, float beta2, float lr, float eps, int32_t mode, void* stream);
+/* pp_adam_upd (mode 0) over up to 32 small tensors of one optimiser group in ONE launch: the *_host arguments are HOST arrays of
+ * n_tensors device pointers / sizes (copied into the kernel's arguments; nothing is dereferenced on the host).  Same arithmetic. */
+int pp_adam_upd_multi(float* const* params_host, const float* const* grads_host, float* const* exp_avg_host,
+                      float* const* exp_avg_sq_host, const int32_t* sizes_host, int32_t n_tensors, int32_t step, float beta1,
+                      float beta2, float lr, float eps, void* stream);
 int pp_tv_add_grad(const float* param_cl, float* grad_cl, const float* mask_cl, int32_t size_x, int32_t size_y,
                    int32_t size_z, int32_t channels, float wx, float wy, float wz, int32_t dense_mode, void* stream);
 int pp_cumdist_thres(const float* dist, float thres, int32_t n_rays, int32_t n_pts, uint8_t* mask, void* stream);

@@ -55,6 +55,8 @@ __global__ __launch_bounds__(256) void k_loss_rays(const float* __restrict__ rgb
     atomicAdd(&loss_out[0], l_mse / (msum * 3.f));
     atomicAdd(&loss_out[1], l_ent * invN);
     atomicAdd(&loss_out[6], l_bce * invN);
+    // [7]: the WEIGHTED sum of all terms (both kernels add their share): object_losses' `loss` without the TV term
+    atomicAdd(&loss_out[7], w_main * (l_mse / (msum * 3.f)) + w_ent * (l_ent * invN) + w_mask * (l_bce * invN));
   }
 }
 
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(256) void k_loss_samples(const float* __restrict__ 
     atomicAdd(&loss_out[3], l_gd * invM / 3.f);
     atomicAdd(&loss_out[4], l_c * invM);
     atomicAdd(&loss_out[5], l_sd * invM);
+    atomicAdd(&loss_out[7], w_eik * (l_eik * invM) + w_dyn * ((l_gd * invM / 3.f + l_c * invM) + l_sd * invM));
   }
 }
 

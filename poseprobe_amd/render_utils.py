@@ -122,6 +122,23 @@ def _adam(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps, 
               float(beta1), float(beta2), float(lr), float(eps), mode, _stream())
 
 
+def adam_upd_multi(tensors, step, beta1, beta2, lr, eps):
+    """adam_upd over a list of (param, grad, exp_avg, exp_avg_sq) tuples of contiguous fp32 CUDA tensors that share step / betas /
+    lr / eps (one optimiser group), 32 per launch (pp_adam_upd_multi)."""
+    import ctypes
+    for i in range(0, len(tensors), 32):
+        chunk = tensors[i:i + 32]
+        n = len(chunk)
+        arr = lambda k: (ctypes.c_void_p * n)(*[c[k].data_ptr() for c in chunk])
+        for c in chunk:
+            for t in c:
+                if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                    raise RuntimeError('adam_upd_multi: tensors must be contiguous fp32 CUDA tensors')
+        sizes = (ctypes.c_int32 * n)(*[c[0].numel() for c in chunk])
+        _lib.call('pp_adam_upd_multi', arr(0), arr(1), arr(2), arr(3), sizes, n, int(step), float(beta1), float(beta2), float(lr),
+                  float(eps), _stream())
+
+
 def adam_upd(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2, lr, eps):
     _adam(param, grad, exp_avg, exp_avg_sq, None, step, beta1, beta2, lr, eps, 0)
 

@@ -47,6 +47,7 @@ class Adam(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             beta1, beta2 = group['betas']
+            small = {}                                  # step -> [(p, g, m, v)]: small dense tensors of the group go out in ONE launch
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -74,8 +75,12 @@ class Adam(torch.optim.Optimizer):
                     per = self.per_lr.to(p.device)
                     per = per.contiguous(memory_format=torch.channels_last_3d).permute(0, 2, 3, 4, 1) if pd.dim() == 5 and not p.is_contiguous() else per.contiguous()
                     render_utils.adam_upd_with_perlr(pd, gd, md, vd, per, state['step'], beta1, beta2, group['lr'], eps)
+                elif pd.numel() <= (1 << 20) and pd.is_contiguous() and gd.is_contiguous() and pd.dtype == torch.float32 and gd.dtype == torch.float32:
+                    small.setdefault(state['step'], []).append((pd, gd, md, vd))
                 else:
                     render_utils.adam_upd(pd, gd, md, vd, state['step'], beta1, beta2, group['lr'], eps)
+            for step, tensors in small.items():         # same arithmetic as adam_upd, up to 32 tensors per launch
+                render_utils.adam_upd_multi(tensors, step, beta1, beta2, group['lr'], group['eps'] * np.sqrt(1 - beta2 ** step))
         return loss
 
 

@@ -403,3 +403,69 @@ def test_remaining_module_surface_names(tmp_path):
     assert np.allclose(u, ax[0][:, None, None] + ax[1][None, :, None] + ax[2][None, None, :], atol=1e-6)
     with pytest.raises(NotImplementedError, match='mcubes'):
         dvgo_ori.extract_geometry(torch.tensor(lo), torch.tensor(hi), 5, 0.0, lambda p: p.sum(-1))
+
+
+def test_fused_object_losses_equal_the_torch_expressions():
+    """losses.object_losses on CUDA tensors runs the two HIP loss kernels (values + gradient of the weighted sum); it must agree with
+    the op-by-op torch expressions (lib/losses.py:34-74) in every scalar, in the total and in the gradient of the total w.r.t. all
+    seven render outputs - and a caller that differentiates an INDIVIDUAL scalar (not done by the reference loop) still gets the
+    right gradient through the fallback."""
+    from poseprobe_amd import losses
+    from poseprobe_amd.config import ConfigDict
+    g = torch.Generator().manual_seed(4)
+    N, M = 300, 2500
+    r = lambda *s: torch.rand(*s, generator=g)
+    base = dict(rgb_marched=r(N, 3), alphainv_cum=r(N) * 0.98 + 0.01, cum_weights=r(N, 1) * 1.1 - 0.05, gradient=torch.randn(M, 3, generator=g),
+                grad_deform=torch.randn(M, 3, 3, generator=g) * 0.1, sdf_correct=torch.randn(M, 1, generator=g) * 0.01,
+                sdf_deform=torch.randn(M, generator=g) * 0.02)
+    base['alphainv_cum'][:5] = torch.tensor([0., 1., 5e-7, 1 - 5e-7, 0.5])          # the clamps' dead zones
+    base['cum_weights'][:4, 0] = torch.tensor([0., 1., 5e-4, 0.9995])
+    base['sdf_correct'][:3, 0] = 0.
+    target, mask = r(N, 3).cuda(), (r(N, 1) < 0.6).float().cuda()
+    cfg = ConfigDict(weight_main=1.0, weight_tv_k0=0.01, weight_mask=0.1)
+    k0_tv = torch.tensor(0.37, device='cuda', requires_grad=True)
+
+    def run(fn, pick=None):
+        mo = {k: v.clone().cuda().requires_grad_(True) for k, v in base.items()}
+        mo['k0_tv'] = k0_tv
+        S, Wt, loss = fn(mo, cfg, target, mask, 1234, 10000, True)
+        obj = loss * 0.1 if pick is None else S[pick] * 2.0 + loss * 0.1
+        grads = torch.autograd.grad(obj, [mo[k] for k in base] + [k0_tv], allow_unused=True)
+        return S, Wt, loss, grads
+
+    S0, W0, l0, g0 = run(losses._object_losses_torch)
+    S1, W1, l1, g1 = run(losses.object_losses)
+    assert list(S0.keys()) == list(S1.keys()) and dict(W0) == dict(W1)
+    for k in S0:
+        assert_close(S1[k].detach().cpu(), S0[k].detach().cpu().numpy(), rtol=2e-5, atol=1e-7, name='loss.' + k)
+    assert_close(l1.detach().cpu(), l0.detach().cpu().numpy(), rtol=2e-5, name='loss')
+    for k, a, b in zip(list(base) + ['k0_tv'], g1, g0):
+        assert_close(a.cpu(), b.cpu().numpy(), rtol=1e-4, atol=1e-9, name='d loss / d ' + k)
+    for pick in ('img_render', 'sdf_deform_constraint'):                  # individual scalar + total: the fallback path
+        _, _, _, ga = run(losses._object_losses_torch, pick)
+        _, _, _, gb = run(losses.object_losses, pick)
+        for k, a, b in zip(list(base) + ['k0_tv'], gb, ga):
+            assert_close(a.cpu(), b.cpu().numpy(), rtol=1e-4, atol=1e-9, name=f'd ({pick} + loss) / d {k}')
+
+
+def test_adam_step_batches_small_tensors_into_one_launch():
+    """utils.Adam.step sends the small tensors of a group through pp_adam_upd_multi (32 per launch): same numbers as one
+    pp_adam_upd per tensor, over several steps and group settings."""
+    from poseprobe_amd import render_utils, utils
+    g = torch.Generator().manual_seed(2)
+    shapes = [(128, 57), (128,), (128, 128), (128,), (3, 128), (3,), (1,)] * 6         # 42 tensors: two launches
+    ps = [torch.randn(*s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone() for p in ps]
+    rm, rv = [torch.zeros_like(p) for p in ref], [torch.zeros_like(p) for p in ref]
+    opt = utils.Adam([dict(params=ps, lr=1e-3, name='net')], betas=(0.9, 0.99))
+    for step in range(1, 4):
+        grads = [torch.randn(*s, generator=g).cuda() * 1e-3 for s in shapes]
+        for p, gr in zip(ps, grads):
+            p.grad = gr
+        opt.step()
+        eps = 1e-8 * np.sqrt(1 - 0.99 ** step)
+        for p, gr, m, v in zip(ref, grads, rm, rv):
+            render_utils.adam_upd(p, gr, m, v, step, 0.9, 0.99, 1e-3, eps)
+    torch.cuda.synchronize()
+    for a, b in zip(ps, ref):
+        assert torch.equal(a.detach(), b)

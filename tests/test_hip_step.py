@@ -274,7 +274,10 @@ def test_geometry_backward_with_fused_priors_is_bit_identical_to_the_two_kernel_
         assert torch.equal(a, b), name
     # block partials meet in float atomics (unordered): scalars up to summation order
     assert torch.allclose(outs[0][3], outs[1][3], rtol=1e-5, atol=1e-9)
-    assert torch.allclose(outs[0][4], outs[1][4], rtol=1e-5, atol=1e-9) and float(outs[1][4][2:6].abs().sum()) > 0
+    assert torch.allclose(outs[0][4][:7], outs[1][4][:7], rtol=1e-5, atol=1e-9) and float(outs[1][4][2:6].abs().sum()) > 0
+    # slot 7 = the weighted total, maintained by pp_loss_rays / pp_loss_samples only (here: the sample terms' share)
+    lo = outs[0][4]
+    assert abs(float(lo[7]) - float(1.0 * lo[2] + w_dyn * (lo[3] + lo[4] + lo[5]))) <= 1e-5 * float(lo[7]) and float(outs[1][4][7]) == 0.0
 
 
 def test_step_with_no_sample_inside_the_box_is_finite_and_leaves_the_data_gradients_zero():
