@@ -584,6 +584,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     ap.add_argument('--no-dual', action='store_true', help='skip the dual-branch (object + scene) leg')
+    ap.add_argument('--no-inference', action='store_true', help='skip the whole-view inference leg')
+    ap.add_argument('--no-fp32', action='store_true', help='skip the fp32-instruction engine leg (second engine, mlp_split = 0)')
     ap.add_argument('--no-dropin', action='store_true', help='skip the drop-in train step leg (Voxurf.forward -> object_losses -> backward -> utils.Adam.step)')
     ap.add_argument('--no-psnr', action='store_true', help='skip the PSNR-parity leg (oracle vs HIP training run)')
     ap.add_argument('--psnr-steps', type=int, default=40, help='long-horizon length of the PSNR-parity leg (>= 25; 96^3 workload, the oracle costs ~0.5-1 s per step and runs twice: itself and its twin)')
@@ -736,7 +738,7 @@ def main():
     from poseprobe_amd import _lib
     split_default = _lib.get_option('mlp_split')
     fp32_path = None
-    if split_default and _lib.get_option('mlp_fused') and not use_dist:
+    if split_default and _lib.get_option('mlp_fused') and not use_dist and not args.no_fp32:
         eng32 = TrainEngine(cfg, V, H, W, N, device=dev, pose_iters=3000, options={'mlp_split': 0})
         eng32.set_views(views['images'], views['masks'], views['Ks'], views['w2c'])
         init_engine_params(eng32, cfg, seed=3)
@@ -881,7 +883,7 @@ def main():
             out['dual_branch_ms_per_step'] = dual['coarse_phase']['ms_per_step']
             out['dual_branch_hierarchical_rays_per_s'] = dual['hierarchical_phase']['rays_per_s']
             out['roofline_scene'] = dual.pop('roofline_scene', None)
-        out['inference'] = inference_leg(dev, G, H, W) if world == 1 else None
+        out['inference'] = inference_leg(dev, G, H, W) if (world == 1 and not args.no_inference) else None
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(G, H, W, V, N, views, args.cpu_budget)
         else:

@@ -133,14 +133,16 @@ class FlatParams:
     """Packed small parameters: [sdf_ab | rgbnet | warp], each segment padded to 64 floats (16-B aligned sub-blocks)."""
     SEG = [('sdf_ab', 2), ('rgbnet', ops.RGBNET_PARAMS), ('warp', ops.WARP_PARAMS)]
 
-    def __init__(self, device):
+    def __init__(self, device, moments=True):
+        """moments=False: parameters + gradients only (the drop-in autograd node, whose optimiser lives outside)."""
         self.off, o = {}, 0
         for name, n in self.SEG:
             self.off[name] = (o, n)
             o += _pad(n)
         self.n = o
         z = lambda: torch.zeros(o, dtype=torch.float32, device=device)
-        self.data, self.grad, self.m, self.v = z(), z(), z(), z()
+        self.data, self.grad = z(), z()
+        self.m, self.v = (z(), z()) if moments else (None, None)
 
     def view(self, name, which='data'):
         o, n = self.off[name]

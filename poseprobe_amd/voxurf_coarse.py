@@ -125,7 +125,7 @@ class _VoxurfRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, ws, inv_s, pe_w, rays_o, rays_d, viewdirs, k0, sdf_alpha, sdf_beta, *mlp):
         core = model._core
-        flat = FlatParams(rays_o.device)
+        flat = FlatParams(rays_o.device, moments=False)
         rg = [(mlp[2 * i], mlp[2 * i + 1]) for i in range(4)]
         wp = [(mlp[8 + 2 * i], mlp[8 + 2 * i + 1]) for i in range(5)]
         flat.load_reference(sdf_alpha, sdf_beta, rg, wp)
@@ -568,6 +568,17 @@ class Voxurf(torch.nn.Module):
         pts = rays_o[mask] + rays_d[mask] * depth[mask]
         return (pts, depth[mask]) if return_depth else pts
 
+    def _pe_weights(self, cfg, progress, dev):
+        """Coarse-to-fine weights of the step on the device.  They are a function of `progress` that is CONSTANT outside the
+        c2f window (all zeros before barf_c2f[0], all ones after barf_c2f[1]): the upload (a pageable host-to-device copy, i.e. a
+        synchronisation point) only happens when the values change."""
+        w = cfg.pe_weights(progress)
+        key = (w.tobytes(), str(dev))
+        cached = getattr(self, '_pe_cache', None)
+        if cached is None or cached[0] != key:
+            self._pe_cache = cached = (key, torch.from_numpy(w).to(dev))
+        return cached[1]
+
     # ---- forward ----------------------------------------------------------------------------------------------
     def forward(self, rays_o, rays_d, viewdirs, use_deform=True, global_step=None, **render_kwargs):
         """voxurf_coarse.py:922-1092.  Extension: render_kwargs['jitter'] ([N] in [0,1)) overrides the internally drawn
@@ -596,7 +607,7 @@ class Voxurf(torch.nn.Module):
         for k in ('t_min', 't_max', 'ray_start', 'count', 'pts', 'ray_id', 'step_k', 'step'):
             setattr(ws, k, sb[k])
         s_val, inv_s = self._inv_s(global_step, is_train)
-        pe_w = torch.from_numpy(cfg.pe_weights(progress)).to(ro.device)
+        pe_w = self._pe_weights(cfg, progress, ro.device)
         self.k0.ensure_layout()
         outs = _VoxurfRender.apply(self, ws, inv_s, pe_w, ro, rd, vd, self.k0.grid, self.sdf_alpha, self.sdf_beta,
                                    *self._mlp_tensors())
@@ -645,7 +656,7 @@ class Voxurf(torch.nn.Module):
         dist = float(np.float32(cfg.stepsize) * np.float32(cfg.voxel_size))
         ws.step = step_id[:].float() * dist
         s_val, inv_s = self._inv_s(global_step, is_train)
-        pe_w = torch.from_numpy(cfg.pe_weights(progress)).to(dev)
+        pe_w = self._pe_weights(cfg, progress, dev)
         self.k0.ensure_layout()
         flat = FlatParams(dev)
         mlp = self._mlp_tensors()
