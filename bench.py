@@ -76,10 +76,10 @@ def launch_ranks(n_gpus, argv, device_count=None, launcher=None, out=None):
 
 
 def pmc_traffic(grid, voxels, sparse):
-    """HBM bytes per launch of k_grid_tv_adam from the COMMITTED rocprofv3 PMC passes (profiles/r02_grid_traffic_sparse.json, r01_grid_traffic*.json:
+    """HBM bytes per launch of k_grid_tv_adam from the COMMITTED rocprofv3 PMC passes (profiles/r03_grid_traffic_sparse.json, r02_..., r01_grid_traffic*.json:
     FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KB -> bytes), only when it was collected for this grid size and for
     this variant of the pass (dense / sparse-gradient).  Not measured by this run (PMC needs its own rocprofv3 pass)."""
-    for name in (('r02_grid_traffic_sparse.json', 'r01_grid_traffic_sparse.json') if sparse else ('r01_grid_traffic.json',)):
+    for name in (('r03_grid_traffic_sparse.json', 'r02_grid_traffic_sparse.json', 'r01_grid_traffic_sparse.json') if sparse else ('r01_grid_traffic.json',)):
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
             if int(rec['grid']) == int(grid) and int(rec['voxels_per_launch']) == int(voxels):

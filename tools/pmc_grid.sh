@@ -2,7 +2,7 @@
 # usage (GPU box): tools/pmc_grid.sh tag   - HBM traffic of k_grid_tv_adam: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /root/repo/gpurun_out/pmc_$1_$c -- python3 /root/repo/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-psnr --no-dual > /root/repo/gpurun_out/pmc_$1_$c.log 2>&1 || exit 1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /root/repo/gpurun_out/pmc_$1_$c -- python3 /root/repo/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-psnr --no-dual --no-dropin --no-inference --no-fp32 > /root/repo/gpurun_out/pmc_$1_$c.log 2>&1 || exit 1
 done
 python3 - <<PY
 import csv, glob, json
