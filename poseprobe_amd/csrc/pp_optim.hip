@@ -121,7 +121,9 @@ __global__ __launch_bounds__(256) void k_grid_tv_adam(const float4* __restrict__
 // output of Voxurf.forward and its gradient arrives through loss.backward()), in the same X-marching form as the fused pass:
 // every parameter element is fetched once, the +-y / +-z neighbours come from the plane being swept.  GRAD = false: tv_out +=
 // sum |forward differences|; GRAD = true: grad += scale * g_scalar[0] * sum of sgn over the 6 neighbours (read-modify-write,
-// non-temporal).  Per step at 160^3: value 45 us (was 102), gradient 130 us (was 385) - bench.py dropin_train_step.
+// non-temporal).  Per step at 160^3: gradient 168-177 us (the element-wise kernel it replaces: 385), value 100 us (102: both are bound by
+// the latency of the dependent neighbour loads, not by bytes; issuing the next plane's loads one iteration ahead measured SLOWER:
+// 261 / 127 us) - bench.py dropin_train_step.
 template <bool GRAD>
 __global__ __launch_bounds__(256) void k_grid_tv_march(const float4* __restrict__ p_in, int X, int Y, int Z, int q4, int n_chunks,
                                                        int chunk_len, int n_virtual, float scale, const float* __restrict__ g_scalar,

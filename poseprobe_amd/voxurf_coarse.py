@@ -140,30 +140,35 @@ class _VoxurfRender(torch.autograd.Function):
         outs = (ws.rgb_marched, ws.alphainv_last, ws.cum_weights.unsqueeze(-1), ws.weights[:M], ws.alpha[:M], ws.rgb[:M],
                 depth, ws.gradient[:M], ws.sdf_deform[:M], ws.grad_deform[:M].reshape(M, 3, 3),
                 ws.warp_out[:M, 3:4], ws.depth_acc)
-        return tuple(o.clone() for o in outs)
+        # k0_tv (lib/voxurf_coarse.py:1067: evaluated on every forward) rides on this node: its gradient is then ADDED IN PLACE to
+        # the colour-grid gradient the render backward produces - a node of its own hands autograd a second dense 196 MB gradient
+        # to allocate, zero-fill and sum (0.3 ms per step at 160^3)
+        C, (X, Y, Z) = k0.shape[1], k0.shape[2:]
+        tv = torch.zeros(1, device=k0.device)
+        ops.grid_tv_value(k0_cl, (X, Y, Z), C, tv)
+        return tuple(o.clone() for o in outs) + ((tv / 3 / k0.numel())[0],)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_rgbm, g_last, g_cw, g_w, g_alpha, g_rgb, g_depth, g_grad, g_sdfd, g_gdef, g_corr, g_nstep):
+    def backward(ctx, g_rgbm, g_last, g_cw, g_w, g_alpha, g_rgb, g_depth, g_grad, g_sdfd, g_gdef, g_corr, g_nstep, g_tv):
         model, ws, flat = ctx.model, ctx.ws, ctx.flat
         core, M, cap = model._core, ws.M, ws.cap
         ws.alloc_backward()
         dev = ws.rays_o.device
 
         def padded(t, width=None):
-            """upstream [M,...] grad -> capacity-sized contiguous buffer (None stays None: the kernels take NULL for 'no
-            gradient').  Rows past M are never read (every kernel stops at the device-side count), so nothing is zero-filled."""
+            """upstream [M,...] gradient as the kernels want it: contiguous fp32, NO copy into a capacity-sized buffer - every
+            kernel stops at the device-side sample count (M rows), so M rows are all that is ever read; None stays None (NULL =
+            'no gradient')."""
             if t is None:
                 return None
-            if M == cap and t.is_contiguous() and t.dtype == torch.float32:
-                return t
-            b = torch.empty((cap,) if width is None else (cap, width), device=dev)
-            b[:M] = t.reshape(M, -1) if width else t.reshape(M)
-            return b
+            return t.reshape(M, width).contiguous().float() if width else t.reshape(M).contiguous().float()
 
-        ws.g_rgbm.copy_(g_rgbm) if g_rgbm is not None else ws.g_rgbm.zero_()
-        ws.g_last.copy_(g_last) if g_last is not None else ws.g_last.zero_()
-        ws.g_cw.copy_(g_cw.reshape(-1)) if g_cw is not None else ws.g_cw.zero_()
+        # ray-level upstream gradients are read where they are (no staging copies)
+        zero = lambda *shape: torch.zeros(*shape, device=dev)
+        ws.g_rgbm = zero(ws.N, 3) if g_rgbm is None else g_rgbm.contiguous().float()
+        ws.g_last = zero(ws.N) if g_last is None else g_last.contiguous().float()
+        ws.g_cw = zero(ws.N) if g_cw is None else g_cw.reshape(-1).contiguous().float()
         # `depth` = t_min / |d| + sum w step and `_n_step` = sum w step share the per-sample path; only `depth` has the ray-level term
         g_depth = None if g_depth is None else g_depth.contiguous().float()
         if g_depth is None and g_nstep is None:
@@ -174,9 +179,17 @@ class _VoxurfRender(torch.autograd.Function):
             g_depth_all = g_nstep.contiguous().float() if g_depth is None else g_depth + g_nstep.contiguous().float()
         gg = padded(g_grad, 3)
 
+        def capacity_sized(t, width=None):
+            """the two upstream gradients that are ADDED to capacity-sized buffers by a torch op (rare: raw_alpha / raw_rgb in a loss)"""
+            if t is None:
+                return None
+            b = torch.zeros((cap,) if width is None else (cap, width), device=dev)
+            b[:M] = t.reshape(M, -1) if width else t.reshape(M)
+            return b
+
         def add_gradient(w):
             if gg is not None:
-                w.g_gradient[:M].add_(gg[:M])
+                w.g_gradient[:M].add_(gg)
 
         k0_grad = torch.zeros_like(ctx.k0, memory_format=torch.channels_last_3d)
         core.backward(ws, channels_last_view(ctx.k0), ctx.sdf_g, flat.view('sdf_ab'), flat.view('rgbnet'), flat.view('warp'),
@@ -184,7 +197,11 @@ class _VoxurfRender(torch.autograd.Function):
                       flat.view('rgbnet', 'grad'), flat.view('warp', 'grad'),
                       g_depth=g_depth_all, g_weights=padded(g_w),
                       g_gradient_ext=add_gradient, g_sdf_deform=padded(g_sdfd), g_grad_deform=padded(g_gdef, 9),
-                      g_correction=padded(g_corr), g_alpha_ext=padded(g_alpha), g_rgb_ext=padded(g_rgb, 3))
+                      g_correction=padded(g_corr), g_alpha_ext=capacity_sized(g_alpha), g_rgb_ext=capacity_sized(g_rgb, 3))
+        if g_tv is not None:                 # d k0_tv / d k0 added in place (read-modify-write of the gradient the scatter just filled)
+            C, (X, Y, Z) = ctx.k0.shape[1], ctx.k0.shape[2:]
+            ops.grid_tv_grad(channels_last_view(ctx.k0), (X, Y, Z), C, 1.0 / (3 * ctx.k0.numel()), g_tv.reshape(1).contiguous().float(),
+                             channels_last_view(k0_grad))
         go, gd, gv = (torch.empty_like(ws.rays_o) for _ in range(3))
         ops.raygen_select_bwd(core.cfg.pp, None, None, None, 0, 0, True, ws.rays_o, ws.rays_d, ws.t_min, ws.ray_start,
                               ws.g_pts, ws.step, ws.g_view_s, None, None, None, g_depth, go, gd, gv, None)
@@ -612,7 +629,7 @@ class Voxurf(torch.nn.Module):
         outs = _VoxurfRender.apply(self, ws, inv_s, pe_w, ro, rd, vd, self.k0.grid, self.sdf_alpha, self.sdf_beta,
                                    *self._mlp_tensors())
         (rgb_marched, alphainv_last, cum_weights, weights, alpha, rgb, depth, gradient, sdf_deform, grad_deform,
-         correction, n_step) = outs
+         correction, n_step, k0_tv) = outs
         if torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad):
             # same value, but with the explicit t_min / |d| term differentiable w.r.t. the ray (voxurf_coarse.py:1057)
             depth = self._entry_distance(rays_o, rays_d, render_kwargs['near'], render_kwargs['far']) / rays_d.norm(dim=-1) + n_step
@@ -625,7 +642,7 @@ class Voxurf(torch.nn.Module):
             'alphainv_cum': alphainv_last, 'weights': weights, 'cum_weights': cum_weights, 'rgb_marched': rgb_marched,
             'normal_marched': normal_marched, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth, 'disp': 1 / depth,
             'mask': sb['keep'].bool(), 'mask_outbbox': torch.zeros(M, dtype=torch.bool, device=ro.device),
-            'gradient': gradient, 's_val': s_val, 'k0_tv': self.k0_total_variation(), 'sdf_deform': sdf_deform,
+            'gradient': gradient, 's_val': s_val, 'k0_tv': k0_tv, 'sdf_deform': sdf_deform,
             'grad_deform': grad_deform, 'sdf_correct': correction,
             '_t_min': ws.t_min, '_n_step': n_step,   # extras (not in the reference dict) for query_sdf_point_wocuda_render
         }
