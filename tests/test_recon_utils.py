@@ -201,3 +201,60 @@ def test_backward_is_complete_over_every_output_of_the_forward_dict():
         if key in d:
             assert prm.grad is not None, name
             assert_close(prm.grad.detach().cpu().numpy(), d[key], name=name, **tol)
+
+
+@pytest.mark.gpu
+def test_zero_crossing_query_on_a_long_ray_and_a_rough_template():
+    """pp_sdf_first_crossing / pp_sdf_crossing_dense_bwd beyond one wavefront of samples per ray (64^3 grid: 76 samples, the
+    first sign change is searched in two ballot rounds) on a ROUGH template (smooth random field: crossings at every depth,
+    several per ray, some rays without any): value and gradient w.r.t. the rays against the oracle."""
+    from oracle import voxurf_oracle as O
+    from poseprobe_amd import synthetic as syn
+    from poseprobe_amd import voxurf_coarse as Model
+    G = 64
+    rs = syn.range_shape()
+    scene = O.Scene(syn.XYZ_MIN, syn.XYZ_MAX, G ** 3, output_range=float(rs.max()), rect_size=rs.tolist())
+    assert scene.n_samples() == 76
+    g = torch.Generator().manual_seed(9)
+    # template: positive everywhere except behind the plane x + y + z = 1.35 near the FAR corner of the box (+ a little smooth noise):
+    # rays along the box diagonal cross it ~67 samples in, rays towards random targets cross it anywhere or not at all
+    lin = [torch.linspace(float(lo), float(hi), G) for lo, hi in zip(syn.XYZ_MIN, syn.XYZ_MAX)]
+    gx, gy, gz = torch.meshgrid(*lin, indexing='ij')
+    noise = torch.nn.functional.interpolate(torch.randn(1, 1, 9, 9, 9, generator=g), size=(G, G, G), mode='trilinear', align_corners=True)
+    sdf = (0.3 - 0.6 * torch.sigmoid((gx + gy + gz - 1.35) / 0.05))[None, None] + 0.02 * noise
+    m = Model.Voxurf(syn.XYZ_MIN, syn.XYZ_MAX, num_voxels=G ** 3, num_voxels_base=G ** 3, alpha_init=1e-2, rgbnet_dim=12, rgbnet_direct=True,
+                     rgbnet_depth=4, rgbnet_width=128, posbase_pe=5, viewbase_pe=1, geo_rgb_dim=3, s_ratio=50, s_start=0.2, barf_c2f=[0.6, 1],
+                     i_train=np.arange(3), N_iters=10000, HW=np.array([[32, 32]] * 3), range_shape=rs, rect_size=rs.tolist(), camera_noise=0.)
+    sd = m.state_dict()
+    sd['sdf.grid'] = sdf.clone()
+    m.load_state_dict(sd)
+    m = m.cuda()
+    N = 257
+    o = torch.randn(N, 3, generator=g) * 0.05 + torch.tensor([-1.2, -1.2, -1.4])          # outside the near corner
+    tgt = (torch.rand(N, 3, generator=g) - 0.5) * torch.tensor([1.3, 1.3, 1.3]) + torch.tensor([0., 0., -0.1])
+    tgt[::2] = torch.tensor([0.6, 0.6, 0.5]) + torch.randn((N + 1) // 2, 3, generator=g) * 0.03    # every other ray: along the diagonal
+    dd = tgt - o
+    dd = dd / dd.norm(dim=-1, keepdim=True)
+    jit = torch.rand(N, generator=g)
+    c_pts = torch.randn(N, 3, generator=g)
+    res = {}
+    for name, dev in (('oracle', 'cpu'), ('hip', 'cuda')):
+        oo, dv = o.clone().to(dev).requires_grad_(True), dd.clone().to(dev).requires_grad_(True)
+        if name == 'oracle':
+            pts, hit, sdf_d = O.query_wodeform(scene, sdf, oo, dv, jit)
+        else:
+            pts, hit, sdf_d = m.query_sdf_point_wocuda_wodeform(oo, dv, global_step=3, keep_dim=True, jitter=jit.cuda(), near=0.24, far=4.8,
+                                                                stepsize=1.5, bg=0)
+        (pts * c_pts.to(dev)).sum().backward()
+        res[name] = (pts.detach().cpu(), hit.cpu(), sdf_d.detach().cpu(), oo.grad.cpu(), dv.grad.cpu())
+    (p0, h0, s0, go0, gd0), (p1, h1, s1, go1, gd1) = res['oracle'], res['hip']
+    first = torch.argmax(((s0[:, :-1] * s0[:, 1:]) <= 0).float(), 1)
+    assert 0.3 < h0.float().mean() < 0.99 and int((first[h0] >= 63).sum()) >= 20, 'need hits, misses and crossings past slot 63'
+    assert_close(s1.numpy(), s0.numpy(), rtol=1e-4, atol=2e-5, name='dense sdf row')
+    same = h0 == h1
+    assert same.float().mean() > 0.98
+    stable = same & ((p0 - p1).abs().amax(-1) < 1e-3)
+    assert stable.float().mean() > 0.97
+    assert_close(p1[stable & h0].numpy(), p0[stable & h0].numpy(), rtol=1e-4, atol=2e-5, name='surface points')
+    assert_close(go1[stable].numpy(), go0[stable].numpy(), rtol=2e-3, atol=1e-5, scaled=1e-3, name='d/d rays_o')
+    assert_close(gd1[stable].numpy(), gd0[stable].numpy(), rtol=2e-3, atol=1e-5, scaled=1e-3, name='d/d rays_d')
