@@ -52,8 +52,11 @@ def render_view(model, H, W, K, c2w, ndc, render_kwargs, flip_x=False, flip_y=Fa
                                                         flip_x=flip_x, flip_y=flip_y)
     ro, rd, vd = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), viewdirs.reshape(-1, 3)
     parts = {k: [] for k in keys}
+    # only per-ray entries are kept of a chunk: the sync-free entry point (same kernels, no host round trip per chunk) serves them
+    ray_level = set(keys) <= {'rgb_marched', 'disp', 'alphainv_cum', 'normal_marched', 'depth', 'cum_weights'} and hasattr(model, 'inference_rays')
+    run = model.inference_rays if ray_level else model.inference
     for b in range(0, ro.shape[0], chunk):
-        out = model.inference(ro[b:b + chunk], rd[b:b + chunk], vd[b:b + chunk], training=False, **render_kwargs)
+        out = run(ro[b:b + chunk], rd[b:b + chunk], vd[b:b + chunk], training=False, **render_kwargs)
         for k in keys:
             if out.get(k) is not None:
                 parts[k].append(out[k])

@@ -696,6 +696,59 @@ class Voxurf(torch.nn.Module):
         }
 
 
+    @torch.no_grad()
+    def inference_rays(self, rays_o, rays_d, viewdirs, global_step=None, **render_kwargs):
+        """The per-RAY outputs of `inference` (rgb_marched, alphainv_cum, cum_weights, depth, disp, normal_marched) WITHOUT the
+        host round trip for the sample count: what a whole-view driver keeps of a chunk (lib/nvs_fun.py:74-85 discards every
+        per-sample entry).  Same kernels on the same samples as `inference` - the chunk's buffers are sized for the sampler's
+        worst case (N (S + 2) samples) and kept on the module, every kernel stops at the device-side count, the normals are
+        composited by the marching kernel itself - so a view is 40 chunks enqueued back to back instead of 40 syncs."""
+        self._check_inputs(rays_o, rays_d, viewdirs)
+        core = self._scene(render_kwargs)
+        cfg = core.cfg
+        is_train = global_step is not None
+        progress = self._set_progress(global_step)
+        N, dev = len(rays_o), rays_o.device
+        ro, rd, vd = rays_o.contiguous().float(), rays_d.contiguous().float(), viewdirs.contiguous().float()
+        sc = N * (cfg.n_samples + 2)
+        cap = (sc + 4095) // 4096 * 4096
+        key = (N, cap, str(dev), id(core))
+        cache = getattr(self, '_ray_cache', None)
+        if cache is None or cache['key'] != key:
+            f, i = dict(device=dev, dtype=torch.float32), dict(device=dev, dtype=torch.int32)
+            ws = Workspace(N, cap, dev, sample_capacity=cap, backward=False, keep_activations=False, ctx=core.ctx)
+            ws.n_steps = torch.empty(N, **i)
+            ws.nrm = torch.empty(cap, 3, **f)
+            ws.normal_marched = torch.empty(N, 3, **f)
+            self._ray_cache = cache = dict(key=key, ws=ws, flat=FlatParams(dev, moments=False))
+        ws, flat = cache['ws'], cache['flat']
+        ws.rays_o, ws.rays_d, ws.viewdirs = ro, rd, vd
+        ops.sample_var(cfg.pp, ro, rd, cap, ws.t_min, ws.t_max, ws.n_steps, ws.ray_start, ws.count, ws.pts, ws.ray_id, ws.step_k)
+        dist = float(np.float32(cfg.stepsize) * np.float32(cfg.voxel_size))
+        torch.mul(ws.step_k, dist, out=ws.step)                     # step_id * dist (fp32 product of an exact integer)
+        s_val, inv_s = self._inv_s(global_step, is_train)
+        pe_w = self._pe_weights(cfg, progress, dev)
+        self.k0.ensure_layout()
+        mlp = self._mlp_tensors()
+        flat.load_reference(self.sdf_alpha, self.sdf_beta, [(mlp[2 * k], mlp[2 * k + 1]) for k in range(4)],
+                            [(mlp[8 + 2 * k], mlp[8 + 2 * k + 1]) for k in range(5)])
+        sdf_g = self.sdf.grid[0, 0].contiguous()
+        ops.warp_fwd(flat.view('warp'), ws.pts, ws.count, ws.cap, cfg.out_range, ws.warp_acts, ws.warp_out, core.ctx)
+        ops.geometry_fwd(cfg.pp, sdf_g, flat.view('sdf_ab'), ws.pts, ws.warp_out, ws.viewdirs, ws.ray_id, ws.count, ws.cap, inv_s,
+                         ws.alpha, ws.gradient, ws.sdf_final, ws.sdf_deform, ws.grad_deform)
+        ops.color_feat_fwd(cfg.pp, channels_last_view(self.k0.grid), ws.pts, ws.viewdirs, ws.ray_id, ws.gradient, pe_w, ws.count,
+                           ws.cap, ws.feat)
+        ops.rgbnet_fwd(flat.view('rgbnet'), ws.feat, ws.count, ws.cap, ws.rgb_acts, ws.rgb, core.ctx)
+        # rows past the count hold stale values: harmless, the marching kernel walks ray_start ranges only
+        torch.div(ws.gradient, ws.gradient.norm(2, -1, keepdim=True) + 1e-6, out=ws.nrm)
+        ops.march_fwd(ws.alpha, ws.rgb, ws.step, ws.nrm, ws.ray_start, N, cfg.bg, ws.weights, ws.T, ws.alphainv_last, ws.i_end,
+                      ws.rgb_marched, ws.rgb_pre, ws.cum_weights, ws.depth_acc, ws.normal_marched)
+        depth = ws.depth_acc.clone()
+        return {'alphainv_cum': ws.alphainv_last.clone(), 'cum_weights': ws.cum_weights.clone().unsqueeze(-1),
+                'rgb_marched': ws.rgb_marched.clone(), 'normal_marched': ws.normal_marched.clone(), 'depth': depth, 'disp': 1 / depth,
+                's_val': s_val}
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # rays (lib/voxurf_coarse.py:1339-1631)
 # ---------------------------------------------------------------------------------------------------------------

@@ -469,3 +469,34 @@ def test_adam_step_batches_small_tensors_into_one_launch():
     torch.cuda.synchronize()
     for a, b in zip(ps, ref):
         assert torch.equal(a.detach(), b)
+
+
+def test_sync_free_ray_inference_equals_inference():
+    """Voxurf.inference_rays (the whole-view driver's chunk call: no host round trip for the sample count, buffers sized for the
+    sampler's worst case and kept on the module, normals composited by the marching kernel) returns the per-ray entries of
+    Voxurf.inference (lib/voxurf_coarse.py:1094-1222) - also on a second call that reuses the cached buffers with a chunk
+    whose sample count is SMALLER (stale rows past the count must not leak into any ray)."""
+    d = load('inference_g24.npz')
+    m = make_model(d)
+    ro, rd, vd = (torch.tensor(d[k]).cuda() for k in ('rays_o', 'rays_d', 'viewdirs'))
+    kw = dict(near=0.24, far=4.8, bg=0, stepsize=1.5, inverse_y=True, flip_x=False, flip_y=False)
+    c = lambda t: t.detach().cpu().numpy()
+    for sel in (slice(None), torch.arange(ro.shape[0] - 1, -1, -1, device='cuda')):     # all rays, then the same count in another order
+        a = m.inference(ro[sel], rd[sel], vd[sel], global_step=None, **kw)
+        b = m.inference_rays(ro[sel], rd[sel], vd[sel], global_step=None, **kw)
+        for k in ('rgb_marched', 'alphainv_cum', 'cum_weights', 'depth', 'disp'):
+            assert a[k].shape == b[k].shape, k
+            assert torch.equal(a[k], b[k]), k                        # same kernels on the same samples: bit-identical
+        assert_close(c(b['normal_marched']), c(a['normal_marched']), rtol=1e-5, atol=1e-6, name='normal_marched')
+    # a chunk that mostly misses the box after a full one: nothing stale survives
+    far = ro.clone()
+    far[::2] += torch.tensor([50.0, 0.0, 0.0], device='cuda')
+    a = m.inference(far, rd, vd, global_step=None, **kw)
+    b = m.inference_rays(far, rd, vd, global_step=None, **kw)
+    for k in ('rgb_marched', 'alphainv_cum', 'depth'):
+        assert torch.equal(a[k], b[k]), k
+    assert_close(c(b['normal_marched']), c(a['normal_marched']), rtol=1e-5, atol=1e-6, name='normal_marched (sparse chunk)')
+    # the reference values of the fixture through the new entry point
+    b = m.inference_rays(ro, rd, vd, global_step=None, **kw)
+    for k in ('alphainv_cum', 'cum_weights', 'rgb_marched', 'normal_marched', 'depth'):
+        assert_close(c(b[k]), d['out.' + k], rtol=1e-4, atol=1e-5, scaled=1e-6, name=k)
