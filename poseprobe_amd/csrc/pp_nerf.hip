@@ -204,6 +204,8 @@ __global__ __launch_bounds__(256) void k_nerf_density_fwd(const float* __restric
 }
 
 // colour head: rgb = sigmoid(h . R1^T + br1) ; 16 lanes per sample
+#include "pp_nerf_trunk.h"
+
 __global__ __launch_bounds__(256) void k_nerf_rgb_fwd(const float* __restrict__ R1, const float* __restrict__ br1,
                                                       const float* __restrict__ h, int M, float* __restrict__ rgb) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -669,6 +671,9 @@ static int nerf_wide_tiles() { return pp_opt(PP_OPT_NERF_BN) == 256; }
 //   nerf_planes        256-wide layers on the second-generation kernel (pp_gemm_planes.h: weights pre-split into LDS images once
 //                      per pass, 128 x 256 tile on eight wavefronts); needs nerf_split and nerf_bitmask; 0 = first generation
 #define NERF_PLANES (pp_opt(PP_OPT_NERF_PLANES) == 1 && NERF_SPLIT && NERF_BITMASK)
+//   nerf_chain         forward pass: the eight feature layers and the density head as ONE kernel that keeps a 128-sample tile in LDS
+//                      across the layers (pp_nerf_trunk.h); needs nerf_planes; 0 = one GEMM per layer
+#define NERF_CHAIN (pp_opt(PP_OPT_NERF_CHAIN) == 1 && NERF_PLANES)
 
 template <int EPI>
 static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, int K, int Nout, const float* bias,
@@ -763,7 +768,11 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
     J.src[8] = params + L.r0; J.n[8] = 128 * 288;
     hipLaunchKernelGGL(k_nerf_wmax, dim3(32, 9), dim3(256), 0, st, J, mx);
     hipLaunchKernelGGL(k_nerf_enc_bound, dim3(n_rays < 256 ? pp_div_up(n_rays, 4) : 64), dim3(256), 0, st, center, ray, depth, n_rays, n_samples, mx);
-    if (NERF_PLANES) {
+    if (NERF_CHAIN) {
+      TrunkPackJobs P;
+      for (int l = 0; l < 8; ++l) { P.src[l] = params + L.w[l]; P.ld[l] = NERF_IN_LD[l]; }
+      hipLaunchKernelGGL(k_pack_trunk, dim3(TR_STEPS * 4), dim3(256), 0, st, P, mx, (int)MX_W0, reinterpret_cast<unsigned char*>(A.wimg[0]));
+    } else if (NERF_PLANES) {
       PlanePackJobs P;
       P.n = 8;
       for (int l = 0; l < 8; ++l) {
@@ -774,15 +783,28 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
   }
   hipLaunchKernelGGL(k_nerf_encode, dim3(pp_div_up(M, 16)), dim3(256), 0, st, center, ray, depth, bands, M,
                      n_samples, A.enc, A.a[3], A.a[7]);
-  const float* in = A.enc;
-  for (int l = 0; l < 8; ++l) {
-    nerf_gemm<EPI_RELU>(st, in, NERF_IN_LD[l], params + L.w[l], NERF_IN_LD[l], NERF_IN_LD[l], 256, params + L.b[l], nullptr, 0,
-                        A.a[l], NERF_OUT_LD[l], count, M, mx ? mx + (l == 0 ? MX_ENC : MX_A0 + l - 1) : nullptr,
-                        mx ? mx + MX_W0 + l : nullptr, mx ? mx + MX_A0 + l : nullptr, A.bits[l], A.wimg[l]);
-    in = A.a[l];
+  if (mx && NERF_CHAIN) {
+    TrunkArgs T;
+    T.enc = A.enc;
+    for (int l = 0; l < 8; ++l) {
+      T.out[l] = A.a[l]; T.ld[l] = NERF_OUT_LD[l]; T.bias[l] = params + L.b[l]; T.bits[l] = reinterpret_cast<uint32_t*>(A.bits[l]);
+    }
+    T.wstream = reinterpret_cast<const unsigned char*>(A.wimg[0]);
+    T.wd = params + L.wd; T.bd = params + L.bd; T.raw = A.raw; T.density = density_samples;
+    T.mx = mx; T.mx_enc = MX_ENC; T.mx_w0 = MX_W0; T.mx_a0 = MX_A0;
+    const int tiles = pp_div_up(M, 128), cus = pp_num_cus();
+    hipLaunchKernelGGL(k_nerf_trunk_fwd, dim3(tiles < cus ? tiles : cus), dim3(512), 0, st, T, count, M);
+  } else {
+    const float* in = A.enc;
+    for (int l = 0; l < 8; ++l) {
+      nerf_gemm<EPI_RELU>(st, in, NERF_IN_LD[l], params + L.w[l], NERF_IN_LD[l], NERF_IN_LD[l], 256, params + L.b[l], nullptr, 0,
+                          A.a[l], NERF_OUT_LD[l], count, M, mx ? mx + (l == 0 ? MX_ENC : MX_A0 + l - 1) : nullptr,
+                          mx ? mx + MX_W0 + l : nullptr, mx ? mx + MX_A0 + l : nullptr, A.bits[l], A.wimg[l]);
+      in = A.a[l];
+    }
+    hipLaunchKernelGGL(k_nerf_density_fwd, dim3(pp_div_up(M, 4)), dim3(256), 0, st, A.a[6], params + L.wd, params + L.bd, M,
+                       A.raw, density_samples);
   }
-  hipLaunchKernelGGL(k_nerf_density_fwd, dim3(pp_div_up(M, 4)), dim3(256), 0, st, A.a[6], params + L.wd, params + L.bd, M,
-                     A.raw, density_samples);
   nerf_gemm<EPI_RELU>(st, A.a[7], 288, params + L.r0, 288, 288, 128, params + L.br0, nullptr, 0, A.h, 128, count, M,
                       mx ? mx + MX_A0 + 7 : nullptr, mx ? mx + MX_R0 : nullptr, nullptr);
   hipLaunchKernelGGL(k_nerf_rgb_fwd, dim3(pp_div_up(M * 16, 256)), dim3(256), 0, st, params + L.r1, params + L.br1, A.h, M,

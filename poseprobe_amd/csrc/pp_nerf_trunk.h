@@ -1,0 +1,298 @@
+// The eight 256-wide feature layers of the scene-branch NeRF (lib/bg_nerf/source/models/frequency_nerf.py:152-170: 63 -> 256 x 8,
+// skip connection at layer 4) as ONE kernel: a work-group carries a 128-sample tile through all eight layers, so a layer's
+// input never comes back from HBM - every layer's output is still WRITTEN (the backward pass needs it), which halves the
+// activation traffic of the layer-by-layer path (pp_gemm_planes.h: 1 KB in + 1 KB out per sample and layer) and removes its
+// per-K-chunk barriers.  Same arithmetic: three fp16 products per fp32 product, fp32 accumulation (pp_gemm_split.h).
+//
+// Data flow per tile
+//   * the activation tile lives in LDS as the split-precision image the matrix instructions read: 8 K-chunks of
+//     [128 rows][32 hi | 32 lo halfs], 16-byte slots XOR-swizzled (pl_slot_off), 128 KB;
+//   * the 64 encoded-point columns (input of layer 0, skip input of layer 4) go through a separate one-chunk image E (16 KB),
+//     fetched from HBM into registers two layers ahead of their use;
+//   * wavefront w of eight owns output columns 32 w .. 32 w + 31 of all 128 rows.  The matrix instructions run TRANSPOSED,
+//     D[n][row] = sum_k W[n][k] X[row][k]: the weights are the first operand and come straight from L2 into registers
+//     (k_pack_trunk lays them out in the order of use, so a wavefront's stream is linear: 4 KB per step, double-buffered one
+//     step ahead), the activations are the second operand, read from the LDS image.  A lane then holds 4 x 4 CONSECUTIVE
+//     output columns of one row per 32 x 32 block: the layer's output goes to HBM as float4 stores and into chunk w of the
+//     NEXT layer's image as 8-byte LDS writes - wavefront w's columns are exactly K-chunk w of the next layer;
+//   * no barrier inside a layer (the image is read-only while a layer runs, weights are private to a wavefront): two per
+//     layer around the in-place rewrite of the image, two per streamed chunk.
+// Scales.  The layer-by-layer path scales a layer's input by the power of two derived from the maximum of the WHOLE tensor,
+// which the fused kernel cannot know before it has finished; it uses the maximum of the TILE (>= as many significant bits),
+// reduced through LDS between the two barriers of the epilogue, and still records the tensor maxima for the backward pass.
+// ReLU masks are written in the layout the data-gradient kernels read (pp_gemm.h gemm_epilogue: 16 rows of a column per
+// 16-bit word): a lane holds 16 columns of one row here, so the 32 x 32 bit block of a wavefront is transposed with
+// v_cmp (the 64-lane ballot of one accumulator register = two columns x 32 rows), a nibble shuffle in scalar registers and
+// v_writelane.
+// The density head (row 0 of the reference's last feature layer applied to layer 6's output) is folded into layer 6's
+// epilogue: per-wavefront partial dot products through LDS, summed in a fixed order.
+#pragma once
+#include "pp_gemm_planes.h"
+
+#define TR_IMG_BYTES (8 * PL_A_BYTES)
+#define TR_STEPS 60                     // K-chunks of the whole trunk: 2 + 8 + 8 + 8 + (2 + 8) + 8 + 8 + 8
+#ifndef TR_DBG
+#define TR_DBG 0      // experiments only: 1 no matrix instructions, 2 no output stores, 3 no mask words, 4 no weight fetches in the loop, 5 no activation reads
+#endif
+#define TR_WSTEP 32768                  // bytes of one step's weights: 256 columns x 32 k x (hi | lo) halfs
+
+struct TrunkArgs {
+  const float* enc;                     // [M][64] encoded points
+  float* out[8];                        // layer outputs, fp32 [M][ld]
+  int ld[8];
+  const float* bias[8];
+  uint32_t* bits[8];                    // ReLU masks (pairs of the 16-bit words of pp_gemm.h)
+  const unsigned char* wstream;         // k_pack_trunk's image
+  const float* wd;                      // density head (NULL: not folded)
+  const float* bd;
+  float* raw;
+  float* density;
+  float* mx;                            // operand-maximum slots
+  int mx_enc, mx_w0, mx_a0;             // slot numbers: encoded points, weights of layer 0 .., outputs of layer 0 ..
+};
+
+__host__ __device__ __forceinline__ void tr_step_layer(int g, int& l, int& kc) {
+  l = g < 2 ? 0 : g < 10 ? 1 : g < 18 ? 2 : g < 26 ? 3 : g < 36 ? 4 : g < 44 ? 5 : g < 52 ? 6 : 7;
+  const int start = l == 0 ? 0 : l < 5 ? 2 + 8 * (l - 1) : 36 + 8 * (l - 5);
+  kc = g - start;
+  if (l == 4) kc = kc < 2 ? 8 + kc : kc - 2;          // the two skip chunks (input columns 256 .. 319) run first
+}
+
+// weights in the order of use: step g, wavefront w, 16-wide half ks, plane (hi | lo), lane -> 8 halfs:
+// W[32 w + (lane & 31)][32 kc + 16 ks + 8 (lane >> 5) .. + 7] scaled by the layer's power of two
+struct TrunkPackJobs { const float* src[8]; int ld[8]; };
+static __global__ __launch_bounds__(256) void k_pack_trunk(TrunkPackJobs J, const float* __restrict__ mx, int mx_w0,
+                                                           unsigned char* __restrict__ dst) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= TR_STEPS * 1024) return;
+  const int lane = e & 63, ks = (e >> 6) & 1, w = (e >> 7) & 7, g = e >> 10;
+  int l, kc;
+  tr_step_layer(g, l, kc);
+  const float s = pp_split_scale(mx[mx_w0 + l]);
+  const float* p = J.src[l] + (size_t)(32 * w + (lane & 31)) * J.ld[l] + kc * 32 + ks * 16 + (lane >> 5) * 8;
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  pp_half8 h, lo;
+  pp_split8(v, s, h, lo);
+  unsigned char* q = dst + (size_t)g * TR_WSTEP + w * 4096 + ks * 2048 + lane * 16;
+  *reinterpret_cast<pp_half8*>(q) = h;
+  *reinterpret_cast<pp_half8*>(q + 1024) = lo;
+}
+
+// one K-chunk: 24 matrix instructions per wavefront on the chunk image `img` and the weight registers wb = {hi, lo} x 2 halves
+__device__ __forceinline__ void tr_step(const unsigned char* img, const pp_half8 (&wb)[4], f32x16 (&acc)[4], int l31, int lh) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    pp_half8 ah[4], al[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = t * 32 + l31;
+      if (TR_DBG == 5) { ah[t] = wb[t]; al[t] = wb[3 - t]; continue; }
+      ah[t] = *reinterpret_cast<const pp_half8*>(img + pl_slot_off(row, ks * 2 + lh));
+      al[t] = *reinterpret_cast<const pp_half8*>(img + pl_slot_off(row, 4 + ks * 2 + lh));
+    }
+    if (TR_DBG == 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t][ks] += (float)ah[t][0] + (float)al[t][1] + (float)wb[ks * 2][2] + (float)wb[ks * 2 + 1][3];
+      continue;
+    }
+    // small terms first; the three products of one block are four instructions apart
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks * 2 + 1], ah[t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks * 2], al[t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks * 2], ah[t], acc[t], 0, 0, 0);
+  }
+}
+
+// lane `lane_` (a literal) of v_ <- the scalar s_
+#define TR_WRITELANE(v_, s_, lane_) asm("v_writelane_b32 %0, %1, %2" : "+v"(v_) : "s"(s_), "n"(lane_))
+#define TR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")   // LDS-only: the loads in flight stay in flight
+
+__global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const int32_t* __restrict__ count, int rcap) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[TR_IMG_BYTES + PL_A_BYTES + 8 * 128 * 4 + 128];
+  unsigned char* const Img = smem;
+  unsigned char* const E = smem + TR_IMG_BYTES;
+  float* const dpart = reinterpret_cast<float*>(E + PL_A_BYTES);             // [8 wavefronts][128 rows]
+  float* const tmax = dpart + 8 * 128;                                        // [8] tile maxima, [8] running maxima, [8] 1 / weight scale
+  float* const lmax = tmax + 8;
+  float* const swl = lmax + 8;
+  const int R = min(count[0], rcap);
+  const int ntiles = (R + 127) / 128;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const float enc_max = T.mx[T.mx_enc];
+  const float sE = pp_split_scale(enc_max);
+  if (tid < 8) { tmax[tid] = 0.f; lmax[tid] = 0.f; swl[tid] = pp_split_scale(T.mx[T.mx_w0 + tid]); }
+
+  // weight stream: this lane's 16 bytes of the four 1 KB pieces of a step; gs = the next step to fetch
+  const unsigned char* const wbase = T.wstream + w * 4096 + lane * 16;
+  int gs = 0;
+  pp_half8 wb0[4], wb1[4];
+#define TR_WLOAD(wb)                                                                                      \
+  do {                                                                                                    \
+    const unsigned char* p_ = wbase + (size_t)gs * TR_WSTEP;                                              \
+    if (TR_DBG != 4 || first_)                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) (wb)[i_] = *reinterpret_cast<const pp_half8*>(p_ + i_ * 1024); \
+    gs = gs + 1 == TR_STEPS ? 0 : gs + 1;                                                                 \
+  } while (0)
+  bool first_ = true;
+  TR_WLOAD(wb0);
+  TR_WLOAD(wb1);
+  first_ = false;
+
+  // encoded points of a tile: thread -> row tid / 4, eight columns at 8 (tid & 3) of both 32-wide chunks
+  float4 pe[4];
+#define TR_ELOAD(tile_)                                                                                   \
+  do {                                                                                                    \
+    const int row_ = min((tile_) * 128 + (tid >> 2), R - 1);                                              \
+    const float* p_ = T.enc + (size_t)row_ * 64 + (tid & 3) * 8;                                          \
+    pe[0] = *reinterpret_cast<const float4*>(p_);                                                         \
+    pe[1] = *reinterpret_cast<const float4*>(p_ + 4);                                                     \
+    pe[2] = *reinterpret_cast<const float4*>(p_ + 32);                                                    \
+    pe[3] = *reinterpret_cast<const float4*>(p_ + 36);                                                    \
+  } while (0)
+#define TR_ECONV(c_, s_)                                                                                  \
+  do {                                                                                                    \
+    const float v_[8] = {pe[2 * (c_)].x, pe[2 * (c_)].y, pe[2 * (c_)].z, pe[2 * (c_)].w,                  \
+                         pe[2 * (c_) + 1].x, pe[2 * (c_) + 1].y, pe[2 * (c_) + 1].z, pe[2 * (c_) + 1].w}; \
+    pp_half8 h_, l_;                                                                                      \
+    pp_split8(v_, (s_), h_, l_);                                                                          \
+    *reinterpret_cast<pp_half8*>(E + pl_slot_off(tid >> 2, tid & 3)) = h_;                                \
+    *reinterpret_cast<pp_half8*>(E + pl_slot_off(tid >> 2, 4 + (tid & 3))) = l_;                          \
+  } while (0)
+  TR_ELOAD((int)blockIdx.x);
+  TR_BARRIER();
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int r0 = tile * 128;
+    float sA = sE;                                      // scale of the current layer's input
+    for (int l = 0; l < 8; ++l) {
+      f32x16 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+      if (l == 0 || l == 4) {                           // the encoded-point columns, one chunk at a time through E
+        TR_ECONV(0, sA);
+        TR_BARRIER();
+        tr_step(E, wb0, acc, l31, lh);
+        TR_WLOAD(wb0);
+        TR_BARRIER();
+        TR_ECONV(1, sA);
+        TR_BARRIER();
+        tr_step(E, wb1, acc, l31, lh);
+        TR_WLOAD(wb1);
+        TR_BARRIER();
+      }
+      if (l == 3) TR_ELOAD(tile);                       // for layer 4 of this tile
+      if (l == 7) TR_ELOAD(tile + (int)gridDim.x);      // for layer 0 of the next one (rows are clamped)
+      if (l > 0) {
+        for (int kc = 0; kc < 8; kc += 2) {
+          tr_step(Img + kc * PL_A_BYTES, wb0, acc, l31, lh);
+          TR_WLOAD(wb0);
+          tr_step(Img + (kc + 1) * PL_A_BYTES, wb1, acc, l31, lh);
+          TR_WLOAD(wb1);
+        }
+      }
+      // ---- epilogue: bias, ReLU, output to HBM, masks, tile maximum
+      const float inv = 1.0f / (sA * swl[l]);
+      const float* __restrict__ bias = T.bias[l] + 32 * w + 4 * lh;
+      float* __restrict__ out = T.out[l];
+      const int ld = T.ld[l];
+      float vmax = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + 8 * q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float4 v;
+          v.x = fmaxf(acc[t][4 * q] * inv + b.x, 0.f);
+          v.y = fmaxf(acc[t][4 * q + 1] * inv + b.y, 0.f);
+          v.z = fmaxf(acc[t][4 * q + 2] * inv + b.z, 0.f);
+          v.w = fmaxf(acc[t][4 * q + 3] * inv + b.w, 0.f);
+          acc[t][4 * q] = v.x; acc[t][4 * q + 1] = v.y; acc[t][4 * q + 2] = v.z; acc[t][4 * q + 3] = v.w;
+          vmax = fmaxf(vmax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+          const int row = r0 + t * 32 + l31;
+          if (row < R && (TR_DBG != 2 || v.x == 123.456f)) *reinterpret_cast<float4*>(out + (size_t)row * ld + 32 * w + 8 * q + 4 * lh) = v;
+        }
+      }
+      if (TR_DBG != 3) {
+        uint32_t* __restrict__ bits = T.bits[l];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          unsigned mv = 0u;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            // ballot: low word = rows 0..31 of column (j & 3) + 8 (j >> 2), high word = the same rows of that column + 4.
+            // word of row half h' of a column = nibbles h', h' + 2, h' + 4, h' + 6 of its 32 row bits
+            const unsigned long long bal = __ballot(acc[t][j] > 0.f);
+            unsigned long long e = bal & 0x0F0F0F0F0F0F0F0FULL, o = (bal >> 4) & 0x0F0F0F0F0F0F0F0FULL;
+            e = (e | (e >> 4)) & 0x00FF00FF00FF00FFULL;
+            o = (o | (o >> 4)) & 0x00FF00FF00FF00FFULL;
+            e = (e | (e >> 8)) & 0x0000FFFF0000FFFFULL;
+            o = (o | (o >> 8)) & 0x0000FFFF0000FFFFULL;
+            const unsigned long long d = e | (o << 16);
+            const int c = (j & 3) + 8 * (j >> 2);
+            const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
+            TR_WRITELANE(mv, dlo, c);
+            TR_WRITELANE(mv, dhi, c + 4);
+          }
+          if (lane < 32) bits[((size_t)(r0 >> 5) + t) * 256 + 32 * w + lane] = mv;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+      if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(tmax + l), __float_as_uint(vmax));
+      if (tid == 0) tmax[(l + 7) & 7] = 0.f;            // the slot of the layer before: read long ago, next written a tile from now
+      const bool dens = l == 6 && T.wd;
+      if (dens) {
+        const float* __restrict__ wd = T.wd + 32 * w + 4 * lh;
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 c = *reinterpret_cast<const float4*>(wd + 8 * q);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            p[t] += acc[t][4 * q] * c.x + acc[t][4 * q + 1] * c.y + acc[t][4 * q + 2] * c.z + acc[t][4 * q + 3] * c.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          p[t] += __shfl_xor(p[t], 32, 64);
+          if (lh == 0) dpart[w * 128 + t * 32 + l31] = p[t];
+        }
+      }
+      TR_BARRIER();                                     // A: every wavefront is done with the image; maximum and partials complete
+      const float tm = tmax[l];
+      if (tid == 0) lmax[l] = fmaxf(lmax[l], tm);
+      if (dens && tid < 128) {
+        float s = T.bd[0];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += dpart[u * 128 + tid];
+        if (r0 + tid < R) { T.raw[r0 + tid] = s; T.density[r0 + tid] = s > 20.f ? s : log1pf(expf(s)); }
+      }
+      if (l < 7) {
+        sA = pp_split_scale(l == 3 ? fmaxf(tm, enc_max) : tm);      // layer 4 reads the encoded points at the same scale
+        unsigned char* const chunk = Img + w * PL_A_BYTES;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            pp_half4 h, lo;
+            pp_split4(make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]), sA, h, lo);
+            const int row = t * 32 + l31;
+            *reinterpret_cast<pp_half4*>(chunk + pl_slot_off(row, q) + 8 * lh) = h;
+            *reinterpret_cast<pp_half4*>(chunk + pl_slot_off(row, 4 + q) + 8 * lh) = lo;
+          }
+      }
+      TR_BARRIER();                                     // B: the next layer's image is complete
+    }
+  }
+  if (tid < 8) atomicMax(reinterpret_cast<unsigned int*>(T.mx + T.mx_a0 + tid), __float_as_uint(lmax[tid]));
+#undef TR_WLOAD
+#undef TR_ELOAD
+#undef TR_ECONV
+}

@@ -709,3 +709,75 @@ def test_scene_kernels_stay_inside_their_buffers(nerf_split):
         assert float(pgrad.abs().max()) > 0
         del acts_a, scr_a, acts, scr
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('R,S', [(1023, 128), (37, 50), (1, 2)])
+def test_scene_trunk_kernel_equals_layer_by_layer_path(R, S):
+    """Option nerf_chain (csrc/pp_nerf_trunk.h: the eight feature layers + density head as one kernel, tile resident in LDS)
+    against the layer-by-layer GEMMs on the same inputs: every stored activation, the raw density and the sample outputs
+    agree to fp32 rounding of a 256..320-term sum (the two paths scale their fp16 operand pairs by different powers of two -
+    tile maximum vs tensor maximum - so they are not bit-identical), the one-bit ReLU masks the data-gradient kernels read
+    agree wherever the activations of both paths have the same state (and ARE that state), and the tensor maxima recorded
+    for the backward pass agree.  Sizes: four tiles per work-group, a ragged last tile, less than one tile."""
+    from poseprobe_amd import bg_nerf, ops
+    dev = 'cuda'
+    opt = bg_nerf.default_options(sample_intvs=S)
+    torch.manual_seed(5)
+    nets = [bg_nerf.NeRF(opt, device=dev, options={'nerf_chain': c}) for c in (1, 0)]
+    g = torch.Generator().manual_seed(R + S)
+    with torch.no_grad():
+        for lin in list(nets[0].mlp_feat) + list(nets[0].mlp_rgb):
+            lin.bias.copy_(0.05 * torch.randn(lin.bias.shape, generator=g))
+        nets[1].flat.data.copy_(nets[0].flat.data)
+    for n in nets:
+        n.progress.data.fill_(0.65)
+    M = R * S
+    center = (torch.randn(R, 3, generator=g) * 0.3).to(dev)
+    ray = torch.randn(R, 3, generator=g).to(dev)
+    depth = ((torch.rand(R, S, generator=g) + torch.arange(S)) / S * 2.0 + 0.4).to(dev).contiguous()
+    count = torch.tensor([M], dtype=torch.int32, device=dev)
+    n_acts, _ = ops.nerf_workspace(M, R)
+    res = []
+    for n in nets:
+        acts = torch.zeros(n_acts, device=dev)
+        rgb, dens = torch.empty(M, 3, device=dev), torch.empty(M, device=dev)
+        ops.nerf_fwd(n.flat, center, ray, depth, n.band_weights(), count, R, S, acts, rgb, dens, n.ctx)
+        torch.cuda.synchronize()
+        res.append((acts, rgb, dens))
+    (a1, rgb1, d1), (a0, rgb0, d0) = res
+    OUT_LD = [256, 256, 256, 320, 256, 256, 256, 288]
+    off = M * 64
+    assert torch.equal(a1[:off], a0[:off])                          # the encoding is the same kernel
+    acts_l = []
+    for l, ld in enumerate(OUT_LD):
+        x1, x0 = a1[off:off + M * ld].view(M, ld)[:, :256], a0[off:off + M * ld].view(M, ld)[:, :256]
+        assert_close(x1, x0, rtol=2e-5, scaled=2e-6, name=f'layer {l} output')
+        acts_l.append((x1, x0))
+        off += M * ld
+    off += M * 128                                                   # colour head hidden layer (compared through rgb)
+    assert_close(a1[off:off + M], a0[off:off + M], rtol=2e-5, scaled=2e-6, name='raw density')
+    off += M
+    mx1, mx0 = a1[off:off + 64], a0[off:off + 64]
+    assert_close(mx1[1:9], mx0[1:9], rtol=2e-5, name='recorded layer maxima')
+    off += 64
+    Mp = (M + 127) // 128 * 128
+    for l in range(8):
+        b1 = a1[off:off + Mp * 8].view(torch.int32)
+        b0 = a0[off:off + Mp * 8].view(torch.int32)
+        off += Mp * 8
+        # unpack: word [row group of 32][column][half] (16 bits), bit j <-> row 32 g + (j & 3) + 8 (j >> 2) + 4 half
+        def states(b):
+            wds = torch.stack([b & 0xFFFF, (b >> 16) & 0xFFFF], -1).view(Mp // 32, 256, 2)
+            j = torch.arange(16, device=dev)
+            bits = ((wds[..., None] >> j) & 1).bool()                 # [g, col, half, j]
+            rows = ((j & 3) + 8 * (j >> 2))[None, :] + 4 * torch.arange(2, device=dev)[:, None]      # [half, j]
+            out = torch.zeros(Mp // 32, 32, 256, dtype=torch.bool, device=dev)
+            out[:, rows.reshape(-1), :] = bits.permute(0, 2, 3, 1).reshape(Mp // 32, 32, 256)
+            return out.view(Mp, 256)[:M]
+        s1, s0 = states(b1), states(b0)
+        x1, x0 = acts_l[l]
+        assert torch.equal(s1, x1 > 0), f'layer {l}: mask bits of the fused kernel are not the states of its own activations'
+        assert torch.equal(s0, x0 > 0)
+        assert int((s1 != s0).sum()) <= max(2, 2e-6 * s1.numel()), f'layer {l}: {int((s1 != s0).sum())} states differ'
+    assert_close(d1, d0, rtol=2e-5, scaled=2e-6, name='density')
+    assert_close(rgb1, rgb0, rtol=0, atol=2e-6, name='rgb samples')
