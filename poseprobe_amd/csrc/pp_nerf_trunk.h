@@ -13,8 +13,9 @@
 //     D[n][row] = sum_k W[n][k] X[row][k]: the weights are the first operand and come straight from L2 into registers
 //     (k_pack_trunk lays them out in the order of use, so a wavefront's stream is linear: 4 KB per step, double-buffered one
 //     step ahead), the activations are the second operand, read from the LDS image.  A lane then holds 4 x 4 CONSECUTIVE
-//     output columns of one row per 32 x 32 block: the layer's output goes to HBM as float4 stores and into chunk w of the
-//     NEXT layer's image as 8-byte LDS writes - wavefront w's columns are exactly K-chunk w of the next layer;
+//     output columns of one row per 32 x 32 block: the layer's output goes into chunk w of the NEXT layer's image as 8-byte
+//     LDS writes - wavefront w's columns are exactly K-chunk w of the next layer - and from there to HBM while the next layer
+//     runs (see the note at the resident chunks); the last layer's output is stored from the accumulators;
 //   * no barrier inside a layer (the image is read-only while a layer runs, weights are private to a wavefront): two per
 //     layer around the in-place rewrite of the image, two per streamed chunk.
 // Scales.  The layer-by-layer path scales a layer's input by the power of two derived from the maximum of the WHOLE tensor,
@@ -32,7 +33,10 @@
 #define TR_IMG_BYTES (8 * PL_A_BYTES)
 #define TR_STEPS 60                     // K-chunks of the whole trunk: 2 + 8 + 8 + 8 + (2 + 8) + 8 + 8 + 8
 #ifndef TR_DBG
-#define TR_DBG 0      // experiments only: 1 no matrix instructions, 2 no output stores, 3 no mask words, 4 no weight fetches in the loop, 5 no activation reads
+#define TR_DBG 0      // experiments only, bit mask: 1 no matrix instructions, 2 no output stores, 4 no mask words, 8 no weight fetches in the loop, 16 no activation reads
+#endif
+#ifndef TR_NT
+#define TR_NT 1       // output stores non-temporal: the 1 GB of activations a pass writes should not push the 2 MB of weights out of L2
 #endif
 #define TR_WSTEP 32768                  // bytes of one step's weights: 256 columns x 32 k x (hi | lo) halfs
 
@@ -87,11 +91,11 @@ __device__ __forceinline__ void tr_step(const unsigned char* img, const pp_half8
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int row = t * 32 + l31;
-      if (TR_DBG == 5) { ah[t] = wb[t]; al[t] = wb[3 - t]; continue; }
+      if (TR_DBG & 16) { ah[t] = wb[t]; al[t] = wb[3 - t]; continue; }
       ah[t] = *reinterpret_cast<const pp_half8*>(img + pl_slot_off(row, ks * 2 + lh));
       al[t] = *reinterpret_cast<const pp_half8*>(img + pl_slot_off(row, 4 + ks * 2 + lh));
     }
-    if (TR_DBG == 1) {
+    if (TR_DBG & 1) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t][ks] += (float)ah[t][0] + (float)al[t][1] + (float)wb[ks * 2][2] + (float)wb[ks * 2 + 1][3];
       continue;
@@ -107,17 +111,19 @@ __device__ __forceinline__ void tr_step(const unsigned char* img, const pp_half8
 }
 
 // lane `lane_` (a literal) of v_ <- the scalar s_
-#define TR_WRITELANE(v_, s_, lane_) asm("v_writelane_b32 %0, %1, %2" : "+v"(v_) : "s"(s_), "n"(lane_))
+// (s_nop: the scalar comes straight from a vector compare; the compiler's hazard recogniser does not look into inline assembly)
+#define TR_WRITELANE(v_, s_, lane_) asm("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(v_) : "s"(s_), "n"(lane_))
 #define TR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")   // LDS-only: the loads in flight stay in flight
 
 __global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const int32_t* __restrict__ count, int rcap) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[TR_IMG_BYTES + PL_A_BYTES + 8 * 128 * 4 + 128];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[TR_IMG_BYTES + PL_A_BYTES + 8 * 128 * 4 + 128 + 9 * 1024 + 64];
   unsigned char* const Img = smem;
   unsigned char* const E = smem + TR_IMG_BYTES;
   float* const dpart = reinterpret_cast<float*>(E + PL_A_BYTES);             // [8 wavefronts][128 rows]
   float* const tmax = dpart + 8 * 128;                                        // [8] tile maxima, [8] running maxima, [8] 1 / weight scale
   float* const lmax = tmax + 8;
   float* const swl = lmax + 8;
+  float* const bl = swl + 16;                                                 // [8][256] biases, [256] density weights (epilogue operands: no global load, no vmcnt wait there)
   const int R = min(count[0], rcap);
   const int ntiles = (R + 127) / 128;
   if ((int)blockIdx.x >= ntiles) return;
@@ -127,6 +133,8 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const in
   const float enc_max = T.mx[T.mx_enc];
   const float sE = pp_split_scale(enc_max);
   if (tid < 8) { tmax[tid] = 0.f; lmax[tid] = 0.f; swl[tid] = pp_split_scale(T.mx[T.mx_w0 + tid]); }
+  if (tid == 0) bl[9 * 256] = T.bd ? T.bd[0] : 0.f;
+  for (int i = tid; i < 9 * 256; i += 512) bl[i] = i < 2048 ? T.bias[i >> 8][i & 255] : (T.wd ? T.wd[i & 255] : 0.f);
 
   // weight stream: this lane's 16 bytes of the four 1 KB pieces of a step; gs = the next step to fetch
   const unsigned char* const wbase = T.wstream + w * 4096 + lane * 16;
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const in
 #define TR_WLOAD(wb)                                                                                      \
   do {                                                                                                    \
     const unsigned char* p_ = wbase + (size_t)gs * TR_WSTEP;                                              \
-    if (TR_DBG != 4 || first_)                                                                            \
+    if (!(TR_DBG & 8) || first_)                                                                           \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) (wb)[i_] = *reinterpret_cast<const pp_half8*>(p_ + i_ * 1024); \
     gs = gs + 1 == TR_STEPS ? 0 : gs + 1;                                                                 \
   } while (0)
@@ -191,16 +199,47 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const in
       if (l == 3) TR_ELOAD(tile);                       // for layer 4 of this tile
       if (l == 7) TR_ELOAD(tile + (int)gridDim.x);      // for layer 0 of the next one (rows are clamped)
       if (l > 0) {
-        for (int kc = 0; kc < 8; kc += 2) {
-          tr_step(Img + kc * PL_A_BYTES, wb0, acc, l31, lh);
-          TR_WLOAD(wb0);
-          tr_step(Img + (kc + 1) * PL_A_BYTES, wb1, acc, l31, lh);
-          TR_WLOAD(wb1);
+        // eight resident chunks, fully unrolled (a rolled loop makes the weight registers loop-carried: the compiler then loads
+        // into temporaries and copies them at the latch behind a vmcnt(0), i.e. no prefetch at all).  Behind each chunk's
+        // matrix instructions the wavefront also sends 16 rows of that chunk - the PREVIOUS layer's output - to HBM from the
+        // image: x = (hi + lo) / s, exactly the operand the matrix instructions consume (22 significant bits), as 128-byte
+        // rows; the write traffic is thereby spread evenly over the kernel instead of arriving in one burst per layer that
+        // every later weight fetch would have to wait behind (vmcnt retires in order).
+        float* __restrict__ outp = T.out[l - 1];
+        const int ldp = T.ld[l - 1];
+        const float invs = 1.0f / sA;
+        const int drow = 16 * w + (lane >> 2), dc8 = lane & 3;
+        const bool dok = r0 + drow < R;
+        float* const dptr = outp + (size_t)(r0 + drow) * ldp + 8 * dc8;
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+          if (kc & 1) { tr_step(Img + kc * PL_A_BYTES, wb1, acc, l31, lh); TR_WLOAD(wb1); }
+          else { tr_step(Img + kc * PL_A_BYTES, wb0, acc, l31, lh); TR_WLOAD(wb0); }
+          if (!(TR_DBG & 2)) {
+            const pp_half8 h = *reinterpret_cast<const pp_half8*>(Img + kc * PL_A_BYTES + pl_slot_off(drow, dc8));
+            const pp_half8 lo = *reinterpret_cast<const pp_half8*>(Img + kc * PL_A_BYTES + pl_slot_off(drow, 4 + dc8));
+            float4 a, b;
+            a.x = ((float)h[0] + (float)lo[0]) * invs; a.y = ((float)h[1] + (float)lo[1]) * invs;
+            a.z = ((float)h[2] + (float)lo[2]) * invs; a.w = ((float)h[3] + (float)lo[3]) * invs;
+            b.x = ((float)h[4] + (float)lo[4]) * invs; b.y = ((float)h[5] + (float)lo[5]) * invs;
+            b.z = ((float)h[6] + (float)lo[6]) * invs; b.w = ((float)h[7] + (float)lo[7]) * invs;
+            if (dok) {
+              if (TR_NT) {
+                typedef float tr_f4 __attribute__((ext_vector_type(4)));
+                const tr_f4 a4 = {a.x, a.y, a.z, a.w}, b4 = {b.x, b.y, b.z, b.w};
+                __builtin_nontemporal_store(a4, reinterpret_cast<tr_f4*>(dptr + 32 * kc));
+                __builtin_nontemporal_store(b4, reinterpret_cast<tr_f4*>(dptr + 32 * kc + 4));
+              } else {
+                *reinterpret_cast<float4*>(dptr + 32 * kc) = a;
+                *reinterpret_cast<float4*>(dptr + 32 * kc + 4) = b;
+              }
+            }
+          }
         }
       }
       // ---- epilogue: bias, ReLU, output to HBM, masks, tile maximum
       const float inv = 1.0f / (sA * swl[l]);
-      const float* __restrict__ bias = T.bias[l] + 32 * w + 4 * lh;
+      const float* const bias = bl + l * 256 + 32 * w + 4 * lh;
       float* __restrict__ out = T.out[l];
       const int ld = T.ld[l];
       float vmax = 0.f;
@@ -217,31 +256,30 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const in
           acc[t][4 * q] = v.x; acc[t][4 * q + 1] = v.y; acc[t][4 * q + 2] = v.z; acc[t][4 * q + 3] = v.w;
           vmax = fmaxf(vmax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
           const int row = r0 + t * 32 + l31;
-          if (row < R && (TR_DBG != 2 || v.x == 123.456f)) *reinterpret_cast<float4*>(out + (size_t)row * ld + 32 * w + 8 * q + 4 * lh) = v;
+          if (l == 7 && row < R && (!(TR_DBG & 2) || v.x == 123.456f)) *reinterpret_cast<float4*>(out + (size_t)row * ld + 32 * w + 8 * q + 4 * lh) = v;   // (layers 0 .. 6 leave through the image)
         }
       }
-      if (TR_DBG != 3) {
+      if (!(TR_DBG & 4)) {
         uint32_t* __restrict__ bits = T.bits[l];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          unsigned mv = 0u;
+          // lane c of rm <- the 32 row bits of column c: the 64-lane compare mask of accumulator register j is rows 0..31 of
+          // column (j & 3) + 8 (j >> 2) in its low word and of that column + 4 in its high word
+          unsigned rm = 0u;
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
-            // ballot: low word = rows 0..31 of column (j & 3) + 8 (j >> 2), high word = the same rows of that column + 4.
-            // word of row half h' of a column = nibbles h', h' + 2, h' + 4, h' + 6 of its 32 row bits
             const unsigned long long bal = __ballot(acc[t][j] > 0.f);
-            unsigned long long e = bal & 0x0F0F0F0F0F0F0F0FULL, o = (bal >> 4) & 0x0F0F0F0F0F0F0F0FULL;
-            e = (e | (e >> 4)) & 0x00FF00FF00FF00FFULL;
-            o = (o | (o >> 4)) & 0x00FF00FF00FF00FFULL;
-            e = (e | (e >> 8)) & 0x0000FFFF0000FFFFULL;
-            o = (o | (o >> 8)) & 0x0000FFFF0000FFFFULL;
-            const unsigned long long d = e | (o << 16);
-            const int c = (j & 3) + 8 * (j >> 2);
-            const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
-            TR_WRITELANE(mv, dlo, c);
-            TR_WRITELANE(mv, dhi, c + 4);
+            const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
+            TR_WRITELANE(rm, blo, (j & 3) + 8 * (j >> 2));
+            TR_WRITELANE(rm, bhi, (j & 3) + 8 * (j >> 2) + 4);
           }
-          if (lane < 32) bits[((size_t)(r0 >> 5) + t) * 256 + 32 * w + lane] = mv;
+          // word of row half h' of a column = nibbles h', h' + 2, h' + 4, h' + 6 of its row bits; all 32 columns at once
+          unsigned e = rm & 0x0F0F0F0Fu, o = (rm >> 4) & 0x0F0F0F0Fu;
+          e = (e | (e >> 4)) & 0x00FF00FFu;
+          o = (o | (o >> 4)) & 0x00FF00FFu;
+          e = (e | (e >> 8)) & 0x0000FFFFu;
+          o = (o | (o >> 8)) & 0x0000FFFFu;
+          if (lane < 32) bits[((size_t)(r0 >> 5) + t) * 256 + 32 * w + lane] = e | (o << 16);
         }
       }
 #pragma unroll
@@ -250,7 +288,7 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const in
       if (tid == 0) tmax[(l + 7) & 7] = 0.f;            // the slot of the layer before: read long ago, next written a tile from now
       const bool dens = l == 6 && T.wd;
       if (dens) {
-        const float* __restrict__ wd = T.wd + 32 * w + 4 * lh;
+        const float* const wd = bl + 2048 + 32 * w + 4 * lh;
         float p[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -269,7 +307,7 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const in
       const float tm = tmax[l];
       if (tid == 0) lmax[l] = fmaxf(lmax[l], tm);
       if (dens && tid < 128) {
-        float s = T.bd[0];
+        float s = bl[9 * 256];
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += dpart[u * 128 + tid];
         if (r0 + tid < R) { T.raw[r0 + tid] = s; T.density[r0 + tid] = s > 20.f ? s : log1pf(expf(s)); }
