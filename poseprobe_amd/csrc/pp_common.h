@@ -34,7 +34,8 @@ enum PPOption {
                                // fewer leave whole CUs to the small kernels that run beside it
   PP_OPT_SIDE_STREAM,          // 1: the weight-gradient kernels of both object-branch MLP chains are forked onto the context's auxiliary stream
                                // (joined by pp_context_join), 2: rgbnet's only, 0 (default): strictly sequential on the caller's stream
-  PP_OPT_NERF_CHAIN,           // scene branch forward: 1 = the eight feature layers + density head as one kernel with the tile resident in LDS (pp_nerf_trunk.h)
+  PP_OPT_NERF_CHAIN,           // scene branch: bit 1 = the eight feature layers + density head of the forward pass as one kernel with the tile resident in LDS
+                               // (pp_nerf_trunk.h), 3 = the data-gradient chain of the backward pass too (0 = one GEMM per layer)
   PP_OPT_COUNT
 };
 

@@ -88,7 +88,8 @@ static const int64_t NERF_WT_FLOATS = 5 * 65536 + 320 * 256 + 256 * 288 + 64 * 2
 static const int64_t NERF_WTIMG_FLOATS = 256 * (128 + 288 + 6 * 256);
 static const int64_t NERF_PART_FLOATS = 512 * 392;       // NERF_PART_WGS x NERF_PART_LD: partial rows of the thin heads' backward kernels
 static int64_t nerf_scratch_floats(int64_t M, int64_t R) {
-  return M * (320 * 2 + 64 * 2) + R * (128 + 32) + NERF_WT_FLOATS + NERF_WTIMG_FLOATS + NERF_PART_FLOATS;
+  // (the last term: d(layer 6) .. d(layer 0) side by side for the fused data-gradient chain, whose weight-gradient products run after it)
+  return M * (320 * 2 + 64 * 2) + R * (128 + 32) + NERF_WT_FLOATS + NERF_WTIMG_FLOATS + NERF_PART_FLOATS + M * 256 * 7;
 }
 
 extern "C" int pp_nerf_workspace(int64_t n_samples, int64_t n_rays, int64_t* acts_floats, int64_t* scratch_floats) {
@@ -673,7 +674,10 @@ static int nerf_wide_tiles() { return pp_opt(PP_OPT_NERF_BN) == 256; }
 #define NERF_PLANES (pp_opt(PP_OPT_NERF_PLANES) == 1 && NERF_SPLIT && NERF_BITMASK)
 //   nerf_chain         forward pass: the eight feature layers and the density head as ONE kernel that keeps a 128-sample tile in LDS
 //                      across the layers (pp_nerf_trunk.h); needs nerf_planes; 0 = one GEMM per layer
-#define NERF_CHAIN (pp_opt(PP_OPT_NERF_CHAIN) == 1 && NERF_PLANES)
+//                      bit 2 (value 3): the data-gradient chain of the backward pass likewise; the ReLU masks then travel in the
+//                      fused kernels' own layout, so both passes of a step must see the same value
+#define NERF_CHAIN ((pp_opt(PP_OPT_NERF_CHAIN) & 1) && NERF_PLANES)
+#define NERF_CHAIN_BWD (pp_opt(PP_OPT_NERF_CHAIN) == 3 && NERF_PLANES)
 
 template <int EPI>
 static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, int K, int Nout, const float* bias,
@@ -770,8 +774,8 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
     hipLaunchKernelGGL(k_nerf_enc_bound, dim3(n_rays < 256 ? pp_div_up(n_rays, 4) : 64), dim3(256), 0, st, center, ray, depth, n_rays, n_samples, mx);
     if (NERF_CHAIN) {
       TrunkPackJobs P;
-      for (int l = 0; l < 8; ++l) { P.src[l] = params + L.w[l]; P.ld[l] = NERF_IN_LD[l]; }
-      hipLaunchKernelGGL(k_pack_trunk, dim3(TR_STEPS * 4), dim3(256), 0, st, P, mx, (int)MX_W0, reinterpret_cast<unsigned char*>(A.wimg[0]));
+      for (int l = 0; l < 8; ++l) { P.src[l] = params + L.w[l]; P.ld[l] = NERF_IN_LD[l]; P.mx_w[l] = MX_W0 + l; }
+      hipLaunchKernelGGL(k_pack_trunk<false>, dim3(TR_STEPS * 4), dim3(256), 0, st, P, mx, reinterpret_cast<unsigned char*>(A.wimg[0]));
     } else if (NERF_PLANES) {
       PlanePackJobs P;
       P.n = 8;
@@ -785,15 +789,18 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
                      n_samples, A.enc, A.a[3], A.a[7]);
   if (mx && NERF_CHAIN) {
     TrunkArgs T;
-    T.enc = A.enc;
+    memset(&T, 0, sizeof(T));
+    T.in = A.enc; T.in_ld = 64;
     for (int l = 0; l < 8; ++l) {
       T.out[l] = A.a[l]; T.ld[l] = NERF_OUT_LD[l]; T.bias[l] = params + L.b[l]; T.bits[l] = reinterpret_cast<uint32_t*>(A.bits[l]);
+      T.bitsr[l] = A.bits[l]; T.mx_w[l] = MX_W0 + l; T.mx_out[l] = MX_A0 + l;
     }
     T.wstream = reinterpret_cast<const unsigned char*>(A.wimg[0]);
     T.wd = params + L.wd; T.bd = params + L.bd; T.raw = A.raw; T.density = density_samples;
-    T.mx = mx; T.mx_enc = MX_ENC; T.mx_w0 = MX_W0; T.mx_a0 = MX_A0;
+    T.mx = mx; T.mx_in = MX_ENC;
     const int tiles = pp_div_up(M, 128), cus = pp_num_cus();
-    hipLaunchKernelGGL(k_nerf_trunk_fwd, dim3(tiles < cus ? tiles : cus), dim3(512), 0, st, T, count, M);
+    if (NERF_CHAIN_BWD) hipLaunchKernelGGL((k_nerf_trunk<false, true>), dim3(tiles < cus ? tiles : cus), dim3(512), 0, st, T, count, M);
+    else hipLaunchKernelGGL((k_nerf_trunk<false, false>), dim3(tiles < cus ? tiles : cus), dim3(512), 0, st, T, count, M);
   } else {
     const float* in = A.enc;
     for (int l = 0; l < 8; ++l) {
@@ -860,7 +867,16 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
   float* mx = NERF_SPLIT ? A.mx : nullptr;
   if (mx) hipMemsetAsync(mx + MX_DH, 0, (MX_DHSUM - MX_DH + 1) * sizeof(float), st);
   const bool planes = mx && NERF_PLANES;
-  if (planes) {
+  const bool chain = mx && NERF_CHAIN_BWD;
+  float* DY[7];                                    // d(pre-activation of layer l), l = 0 .. 6, for the fused chain
+  for (int l = 0; l < 7; ++l) DY[l] = part + NERF_PART_FLOATS + (size_t)l * M * 256;
+  if (chain) {
+    // the chain's weights in its order of use, read transposed straight from the parameters: R0 (rows = hidden units), W7 .. W1
+    TrunkPackJobs J;
+    J.src[0] = params + L.r0; J.ld[0] = 288; J.mx_w[0] = MX_R0;
+    for (int s_ = 1; s_ < 8; ++s_) { J.src[s_] = params + L.w[8 - s_]; J.ld[s_] = NERF_IN_LD[8 - s_]; J.mx_w[s_] = MX_W0 + 8 - s_; }
+    hipLaunchKernelGGL(k_pack_trunk<true>, dim3(TR_STEPS * 4), dim3(256), 0, st, J, mx, reinterpret_cast<unsigned char*>(r0t_img));
+  } else if (planes) {
     PlanePackJobs P;
     P.n = 8;
     P.src[0] = R0T; P.dst[0] = r0t_img; P.ld[0] = 128; P.K[0] = 128; P.mx_slot[0] = MX_R0;
@@ -882,36 +898,69 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
   hipLaunchKernelGGL(k_nerf_ray_sum, dim3(R < 512 ? R : 512), dim3(512), 0, st, dH, R, S, dHsum, slot(MX_DHSUM));
   nerf_gemm<EPI_PLAIN>(st, dHsum, 128, R0T + 256 * 128, 128, 128, 32, nullptr, nullptr, 0, dView, 32, count, R, slot(MX_DHSUM),
                        slot(MX_R0), nullptr);
-  // last feature layer: columns 0..255 through the colour head, column 256 from the density
-  nerf_gemm<EPI_MASK>(st, dH, 128, R0T, 128, 128, 256, nullptr, A.a[7], 288, P, 288, count, M, slot(MX_DH), slot(MX_R0),
-                      slot(MX_P), A.bits[7], planes ? r0t_img : nullptr);
-  {
-    const int wgs = min(pp_div_up(M, NERF_DSTRIP), NERF_PART_WGS);
-    hipLaunchKernelGGL(k_nerf_density_bwd, dim3(wgs), dim3(512), 0, st, A.a[6], A.raw, g_density_samples, M, P, part);
-    hipLaunchKernelGGL(k_nerf_part_finish, dim3(pp_div_up(258, 64)), dim3(1024), 0, st, part, wgs, params_grad + L.wd, 256, params_grad + L.bd, 1,
-                       slot(MX_P));
+  if (chain) {
+    // d raw (column 256 of P) and the density head's own gradients first: the chain reads that column
+    {
+      const int wgs = min(pp_div_up(M, NERF_DSTRIP), NERF_PART_WGS);
+      hipLaunchKernelGGL(k_nerf_density_bwd, dim3(wgs), dim3(512), 0, st, A.a[6], A.raw, g_density_samples, M, P, part);
+      hipLaunchKernelGGL(k_nerf_part_finish, dim3(pp_div_up(258, 64)), dim3(1024), 0, st, part, wgs, params_grad + L.wd, 256, params_grad + L.bd, 1,
+                         slot(MX_P));
+    }
+    // d(layer 7) .. d(layer 0) in one kernel (pp_nerf_trunk.h), each written once for the weight-gradient products below
+    TrunkArgs T;
+    memset(&T, 0, sizeof(T));
+    T.in = dH; T.in_ld = 128;
+    T.out[0] = P; T.ld[0] = 288; T.mx_w[0] = MX_R0; T.mx_out[0] = MX_P; T.bitsr[0] = A.bits[7];
+    for (int s_ = 1; s_ < 8; ++s_) {
+      T.out[s_] = DY[7 - s_]; T.ld[s_] = 256; T.mx_w[s_] = MX_W0 + 8 - s_; T.mx_out[s_] = MX_DY6 + s_ - 1; T.bitsr[s_] = A.bits[7 - s_];
+    }
+    T.wstream = reinterpret_cast<const unsigned char*>(r0t_img);
+    T.wd = params + L.wd; T.draw = P + 256; T.draw_ld = 288;
+    T.mx = mx; T.mx_in = MX_DH;
+    const int tiles = pp_div_up(M, 128), cus = pp_num_cus();
+    hipLaunchKernelGGL((k_nerf_trunk<true, false>), dim3(tiles < cus ? tiles : cus), dim3(512), 0, st, T, count, M);
+    nerf_gemm_tn(st, P, 288, 256, A.a[6], 256, 256, params_grad + L.w[7], params_grad + L.b[7], count, M, slot(MX_P), slot(MX_A0 + 6));
+    for (int l = 6; l >= 1; --l)
+      nerf_gemm_tn(st, DY[l], 256, 256, A.a[l - 1], NERF_OUT_LD[l - 1], NERF_IN_LD[l], params_grad + L.w[l], params_grad + L.b[l], count, M,
+                   slot(MX_DY6 + 6 - l), slot(MX_A0 + l - 1));
+    nerf_gemm<EPI_PLAIN>(st, DY[4], 256, WT[4] + 256 * 256, 256, 256, 64, nullptr, nullptr, 0, dEncS, 64, count, M,
+                         slot(MX_DY6 + 2), slot(MX_W0 + 4), nullptr);
+    nerf_gemm_tn(st, DY[0], 256, 256, A.enc, 64, 64, params_grad + L.w[0], params_grad + L.b[0], count, M, slot(MX_DY6 + 6),
+                 slot(MX_ENC));
+    nerf_gemm<EPI_PLAIN>(st, DY[0], 256, WT[0], 256, 256, 64, nullptr, nullptr, 0, dEnc0, 64, count, M, slot(MX_DY6 + 6),
+                         slot(MX_W0), nullptr);
+  } else {
+    // last feature layer: columns 0..255 through the colour head, column 256 from the density
+    nerf_gemm<EPI_MASK>(st, dH, 128, R0T, 128, 128, 256, nullptr, A.a[7], 288, P, 288, count, M, slot(MX_DH), slot(MX_R0),
+                        slot(MX_P), A.bits[7], planes ? r0t_img : nullptr);
+    {
+      const int wgs = min(pp_div_up(M, NERF_DSTRIP), NERF_PART_WGS);
+      hipLaunchKernelGGL(k_nerf_density_bwd, dim3(wgs), dim3(512), 0, st, A.a[6], A.raw, g_density_samples, M, P, part);
+      hipLaunchKernelGGL(k_nerf_part_finish, dim3(pp_div_up(258, 64)), dim3(1024), 0, st, part, wgs, params_grad + L.wd, 256, params_grad + L.bd, 1,
+                         slot(MX_P));
+    }
+    nerf_gemm_tn(st, P, 288, 256, A.a[6], 256, 256, params_grad + L.w[7], params_grad + L.b[7], count, M, slot(MX_P), slot(MX_A0 + 6));
+    nerf_gemm<EPI_MASK>(st, P, 288, WT[7], 288, 288, 256, nullptr, A.a[6], 256, Q, 256, count, M, slot(MX_P), slot(MX_W0 + 7),
+                        slot(MX_DY6), A.bits[6], planes ? wt7_img : nullptr);
+    float* cur = Q;
+    float* nxt = P;
+    for (int l = 6; l >= 1; --l) {                   // cur = d(pre-activation of layer l), [M][256]
+      const float* x = A.a[l - 1];
+      const int ldx = NERF_OUT_LD[l - 1];            // 320 for layer 4's input (features + skip columns)
+      nerf_gemm_tn(st, cur, 256, 256, x, ldx, NERF_IN_LD[l], params_grad + L.w[l], params_grad + L.b[l], count, M,
+                   slot(MX_DY6 + 6 - l), slot(MX_A0 + l - 1));
+      nerf_gemm<EPI_MASK>(st, cur, 256, WT[l], 256, 256, 256, nullptr, x, ldx, nxt, 256, count, M, slot(MX_DY6 + 6 - l),
+                          slot(MX_W0 + l), slot(MX_DY6 + 7 - l), A.bits[l - 1], planes ? wt_img[l] : nullptr);
+      if (l == 4)                                    // skip columns: gradient of the encoding, no activation in between
+        nerf_gemm<EPI_PLAIN>(st, cur, 256, WT[4] + 256 * 256, 256, 256, 64, nullptr, nullptr, 0, dEncS, 64, count, M,
+                             slot(MX_DY6 + 2), slot(MX_W0 + 4), nullptr);
+      float* t = cur; cur = nxt; nxt = t;
+    }
+    nerf_gemm_tn(st, cur, 256, 256, A.enc, 64, 64, params_grad + L.w[0], params_grad + L.b[0], count, M, slot(MX_DY6 + 6),
+                 slot(MX_ENC));
+    nerf_gemm<EPI_PLAIN>(st, cur, 256, WT[0], 256, 256, 64, nullptr, nullptr, 0, dEnc0, 64, count, M, slot(MX_DY6 + 6),
+                         slot(MX_W0), nullptr);
   }
-  nerf_gemm_tn(st, P, 288, 256, A.a[6], 256, 256, params_grad + L.w[7], params_grad + L.b[7], count, M, slot(MX_P), slot(MX_A0 + 6));
-  nerf_gemm<EPI_MASK>(st, P, 288, WT[7], 288, 288, 256, nullptr, A.a[6], 256, Q, 256, count, M, slot(MX_P), slot(MX_W0 + 7),
-                      slot(MX_DY6), A.bits[6], planes ? wt7_img : nullptr);
-  float* cur = Q;
-  float* nxt = P;
-  for (int l = 6; l >= 1; --l) {                   // cur = d(pre-activation of layer l), [M][256]
-    const float* x = A.a[l - 1];
-    const int ldx = NERF_OUT_LD[l - 1];            // 320 for layer 4's input (features + skip columns)
-    nerf_gemm_tn(st, cur, 256, 256, x, ldx, NERF_IN_LD[l], params_grad + L.w[l], params_grad + L.b[l], count, M,
-                 slot(MX_DY6 + 6 - l), slot(MX_A0 + l - 1));
-    nerf_gemm<EPI_MASK>(st, cur, 256, WT[l], 256, 256, 256, nullptr, x, ldx, nxt, 256, count, M, slot(MX_DY6 + 6 - l),
-                        slot(MX_W0 + l), slot(MX_DY6 + 7 - l), A.bits[l - 1], planes ? wt_img[l] : nullptr);
-    if (l == 4)                                    // skip columns: gradient of the encoding, no activation in between
-      nerf_gemm<EPI_PLAIN>(st, cur, 256, WT[4] + 256 * 256, 256, 256, 64, nullptr, nullptr, 0, dEncS, 64, count, M,
-                           slot(MX_DY6 + 2), slot(MX_W0 + 4), nullptr);
-    float* t = cur; cur = nxt; nxt = t;
-  }
-  nerf_gemm_tn(st, cur, 256, 256, A.enc, 64, 64, params_grad + L.w[0], params_grad + L.b[0], count, M, slot(MX_DY6 + 6),
-               slot(MX_ENC));
-  nerf_gemm<EPI_PLAIN>(st, cur, 256, WT[0], 256, 256, 64, nullptr, nullptr, 0, dEnc0, 64, count, M, slot(MX_DY6 + 6),
-                       slot(MX_W0), nullptr);
   hipLaunchKernelGGL(k_nerf_encode_bwd, dim3(R), b, 0, st, A.enc, dEnc0, dEncS, dView, A.a[7], ray, depth, R, S, g_center,
                      g_ray);
   PP_CHECK_LAUNCH();

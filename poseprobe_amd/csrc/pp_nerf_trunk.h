@@ -1,61 +1,70 @@
 // The eight 256-wide feature layers of the scene-branch NeRF (lib/bg_nerf/source/models/frequency_nerf.py:152-170: 63 -> 256 x 8,
-// skip connection at layer 4) as ONE kernel: a work-group carries a 128-sample tile through all eight layers, so a layer's
-// input never comes back from HBM - every layer's output is still WRITTEN (the backward pass needs it), which halves the
-// activation traffic of the layer-by-layer path (pp_gemm_planes.h: 1 KB in + 1 KB out per sample and layer) and removes its
-// per-K-chunk barriers.  Same arithmetic: three fp16 products per fp32 product, fp32 accumulation (pp_gemm_split.h).
+// skip connection at layer 4) as ONE kernel, and their data-gradient chain as one more: a work-group carries a 128-sample tile
+// through all eight stages, so a stage's input never comes back from HBM - every stage's output is still WRITTEN (the backward
+// pass / the weight-gradient products need it), which halves the activation traffic of the layer-by-layer path
+// (pp_gemm_planes.h: 1 KB in + 1 KB out per sample and layer) and removes its per-K-chunk barriers.  Same arithmetic: three
+// fp16 products per fp32 product, fp32 accumulation (pp_gemm_split.h).
 //
 // Data flow per tile
 //   * the activation tile lives in LDS as the split-precision image the matrix instructions read: 8 K-chunks of
 //     [128 rows][32 hi | 32 lo halfs], 16-byte slots XOR-swizzled (pl_slot_off), 128 KB;
-//   * the 64 encoded-point columns (input of layer 0, skip input of layer 4) go through a separate one-chunk image E (16 KB),
-//     fetched from HBM into registers two layers ahead of their use;
+//   * what enters a chain from HBM - the 64 encoded-point columns (input of layer 0, skip input of layer 4), the 128 columns of
+//     the colour head's hidden gradient in the backward chain - goes through a separate one-chunk image E (16 KB), fetched into
+//     registers well ahead of its use;
 //   * wavefront w of eight owns output columns 32 w .. 32 w + 31 of all 128 rows.  The matrix instructions run TRANSPOSED,
 //     D[n][row] = sum_k W[n][k] X[row][k]: the weights are the first operand and come straight from L2 into registers
 //     (k_pack_trunk lays them out in the order of use, so a wavefront's stream is linear: 4 KB per step, double-buffered one
 //     step ahead), the activations are the second operand, read from the LDS image.  A lane then holds 4 x 4 CONSECUTIVE
-//     output columns of one row per 32 x 32 block: the layer's output goes into chunk w of the NEXT layer's image as 8-byte
-//     LDS writes - wavefront w's columns are exactly K-chunk w of the next layer - and from there to HBM while the next layer
-//     runs (see the note at the resident chunks); the last layer's output is stored from the accumulators;
-//   * no barrier inside a layer (the image is read-only while a layer runs, weights are private to a wavefront): two per
-//     layer around the in-place rewrite of the image, two per streamed chunk.
-// Scales.  The layer-by-layer path scales a layer's input by the power of two derived from the maximum of the WHOLE tensor,
-// which the fused kernel cannot know before it has finished; it uses the maximum of the TILE (>= as many significant bits),
-// reduced through LDS between the two barriers of the epilogue, and still records the tensor maxima for the backward pass.
-// ReLU masks are written in the layout the data-gradient kernels read (pp_gemm.h gemm_epilogue: 16 rows of a column per
-// 16-bit word): a lane holds 16 columns of one row here, so the 32 x 32 bit block of a wavefront is transposed with
-// v_cmp (the 64-lane ballot of one accumulator register = two columns x 32 rows), a nibble shuffle in scalar registers and
-// v_writelane.
+//     output columns of one row per 32 x 32 block: the stage's output goes into chunk w of the NEXT stage's image as 8-byte
+//     LDS writes - wavefront w's columns are exactly K-chunk w of the next stage - and from there to HBM while the next stage
+//     runs (see the note at the resident chunks); the last stage's output is stored from the accumulators;
+//   * no barrier inside a stage (the image is read-only while a stage runs, weights are private to a wavefront): two per
+//     stage around the in-place rewrite of the image, two per streamed chunk.
+// Scales.  The layer-by-layer path scales a GEMM's input by the power of two derived from the maximum of the WHOLE tensor,
+// which a fused kernel cannot know before it has finished; it uses the maximum of the TILE (>= as many significant bits),
+// reduced through LDS between the two barriers of the epilogue, and still records the tensor maxima for the kernels downstream.
+// ReLU masks: one bit per activation, 32 bytes per sample and layer either way.  MROW = false writes the layout the
+// layer-by-layer data-gradient kernels read (pp_gemm.h gemm_epilogue: 16 rows of a column per 16-bit word; a lane holds 16
+// columns of one row here, so the 32 x 32 bit block of a wavefront is transposed with v_cmp - the 64-lane mask of one
+// accumulator register = two columns x 32 rows -, v_writelane and a nibble shuffle); MROW = true writes the lane's own 16
+// columns as one word, [row][wavefront][lane half], which is what the fused backward chain reads back in the same lane.
 // The density head (row 0 of the reference's last feature layer applied to layer 6's output) is folded into layer 6's
-// epilogue: per-wavefront partial dot products through LDS, summed in a fixed order.
+// epilogue: per-wavefront partial dot products through LDS, summed in a fixed order; its gradient enters the backward chain
+// as the rank-1 term d raw[row] * wd[k] in the epilogue of the stage that produces d(layer 6).
 #pragma once
 #include "pp_gemm_planes.h"
 
 #define TR_IMG_BYTES (8 * PL_A_BYTES)
-#define TR_STEPS 60                     // K-chunks of the whole trunk: 2 + 8 + 8 + 8 + (2 + 8) + 8 + 8 + 8
+#define TR_STEPS 60                     // K-chunks of a chain: forward 2 + 8 + 8 + 8 + (2 + 8) + 8 + 8 + 8, backward 4 + 7 x 8
 #ifndef TR_DBG
 #define TR_DBG 0      // experiments only, bit mask: 1 no matrix instructions, 2 no output stores, 4 no mask words, 8 no weight fetches in the loop, 16 no activation reads
 #endif
 #ifndef TR_NT
-#define TR_NT 1       // output stores non-temporal: the 1 GB of activations a pass writes should not push the 2 MB of weights out of L2
+#define TR_NT 1       // output stores non-temporal: the 1 GB of activations a pass writes should not push the 2 MB of weights out of L2 (508 -> 434 us)
 #endif
 #define TR_WSTEP 32768                  // bytes of one step's weights: 256 columns x 32 k x (hi | lo) halfs
 
 struct TrunkArgs {
-  const float* enc;                     // [M][64] encoded points
-  float* out[8];                        // layer outputs, fp32 [M][ld]
+  const float* in;                      // what the chain reads from HBM: forward [M][64] encoded points, backward [M][128] d(hidden of the colour head)
+  int in_ld;
+  float* out[8];                        // stage outputs, fp32 [M][ld]
   int ld[8];
-  const float* bias[8];
-  uint32_t* bits[8];                    // ReLU masks (pairs of the 16-bit words of pp_gemm.h)
+  const float* bias[8];                 // forward
+  uint32_t* bits[8];                    // forward, MROW = false: ReLU masks in the layer-by-layer layout (pairs of its 16-bit words)
+  uint16_t* bitsr[8];                   // MROW: [row][8 wavefronts][2 lane halves] words; forward writes stage s's, backward reads the mask of stage s's OUTPUT
   const unsigned char* wstream;         // k_pack_trunk's image
-  const float* wd;                      // density head (NULL: not folded)
+  const float* wd;                      // density head weights (forward: NULL = not folded; backward: the rank-1 term)
   const float* bd;
   float* raw;
   float* density;
+  const float* draw;                    // backward: d raw of row r at draw[r * draw_ld]
+  int draw_ld;
   float* mx;                            // operand-maximum slots
-  int mx_enc, mx_w0, mx_a0;             // slot numbers: encoded points, weights of layer 0 .., outputs of layer 0 ..
+  int mx_in;                            // slot of `in`
+  int mx_w[8], mx_out[8];               // per stage: slot of the weights, slot recording the output
 };
 
-__host__ __device__ __forceinline__ void tr_step_layer(int g, int& l, int& kc) {
+__host__ __device__ __forceinline__ void tr_step_layer(int g, int& l, int& kc) {      // forward: step -> layer, K-chunk
   l = g < 2 ? 0 : g < 10 ? 1 : g < 18 ? 2 : g < 26 ? 3 : g < 36 ? 4 : g < 44 ? 5 : g < 52 ? 6 : 7;
   const int start = l == 0 ? 0 : l < 5 ? 2 + 8 * (l - 1) : 36 + 8 * (l - 5);
   kc = g - start;
@@ -63,19 +72,30 @@ __host__ __device__ __forceinline__ void tr_step_layer(int g, int& l, int& kc) {
 }
 
 // weights in the order of use: step g, wavefront w, 16-wide half ks, plane (hi | lo), lane -> 8 halfs:
-// W[32 w + (lane & 31)][32 kc + 16 ks + 8 (lane >> 5) .. + 7] scaled by the layer's power of two
-struct TrunkPackJobs { const float* src[8]; int ld[8]; };
-static __global__ __launch_bounds__(256) void k_pack_trunk(TrunkPackJobs J, const float* __restrict__ mx, int mx_w0,
-                                                           unsigned char* __restrict__ dst) {
+// forward   W_l[32 w + (lane & 31)][32 kc + 16 ks + 8 (lane >> 5) .. + 7]            (src[l] = W_l, [256][ld])
+// backward  stage s = 0: R0[i][o], stages 1 .. 7: W_{8 - s}[i][o] with o = 32 w + (lane & 31), i = 32 kc + 16 ks + 8 (lane >> 5) .. + 7
+//           (src[s] = the stage's matrix with rows i, [.][ld]: the transposed read happens here, once per pass)
+// scaled by the matrix' power of two (slot mx_w[stage])
+struct TrunkPackJobs { const float* src[8]; int ld[8]; int mx_w[8]; };
+template <bool BWD>
+static __global__ __launch_bounds__(256) void k_pack_trunk(TrunkPackJobs J, const float* __restrict__ mx, unsigned char* __restrict__ dst) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= TR_STEPS * 1024) return;
   const int lane = e & 63, ks = (e >> 6) & 1, w = (e >> 7) & 7, g = e >> 10;
   int l, kc;
-  tr_step_layer(g, l, kc);
-  const float s = pp_split_scale(mx[mx_w0 + l]);
-  const float* p = J.src[l] + (size_t)(32 * w + (lane & 31)) * J.ld[l] + kc * 32 + ks * 16 + (lane >> 5) * 8;
-  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  if (BWD) { l = g < 4 ? 0 : 1 + ((g - 4) >> 3); kc = g < 4 ? g : (g - 4) & 7; }
+  else tr_step_layer(g, l, kc);
+  const float s = pp_split_scale(mx[J.mx_w[l]]);
+  const int o = 32 * w + (lane & 31), i0 = kc * 32 + ks * 16 + (lane >> 5) * 8;
+  float v[8];
+  if (BWD) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = J.src[l][(size_t)(i0 + u) * J.ld[l] + o];
+  } else {
+    const float* p = J.src[l] + (size_t)o * J.ld[l] + i0;
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
   pp_half8 h, lo;
   pp_split8(v, s, h, lo);
   unsigned char* q = dst + (size_t)g * TR_WSTEP + w * 4096 + ks * 2048 + lane * 16;
@@ -111,30 +131,35 @@ __device__ __forceinline__ void tr_step(const unsigned char* img, const pp_half8
 }
 
 // lane `lane_` (a literal) of v_ <- the scalar s_
-// (s_nop: the scalar comes straight from a vector compare; the compiler's hazard recogniser does not look into inline assembly)
+// (s_nop: the scalar comes straight from a vector compare; the compiler's hazard recogniser does not look into inline assembly,
+// and without the wait states the lane receives the PREVIOUS compare's mask - found by the gradient parity test)
 #define TR_WRITELANE(v_, s_, lane_) asm("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(v_) : "s"(s_), "n"(lane_))
 #define TR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")   // LDS-only: the loads in flight stay in flight
 
-__global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const int32_t* __restrict__ count, int rcap) {
+// BWD = false: stages = layers 0 .. 7 (bias, ReLU, masks out, density head at layer 6), streamed chunks: 2 in front of layers 0 and 4
+// BWD = true:  stage 0 = d(layer 7) from d(hidden) through R0 (4 streamed chunks), stage s = d(layer 7 - s) through W_{8 - s};
+//              epilogue = the mask of the stage's output (+ the density term at stage 1)
+template <bool BWD, bool MROW>
+__global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_t* __restrict__ count, int rcap) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[TR_IMG_BYTES + PL_A_BYTES + 8 * 128 * 4 + 128 + 9 * 1024 + 64];
   unsigned char* const Img = smem;
   unsigned char* const E = smem + TR_IMG_BYTES;
   float* const dpart = reinterpret_cast<float*>(E + PL_A_BYTES);             // [8 wavefronts][128 rows]
-  float* const tmax = dpart + 8 * 128;                                        // [8] tile maxima, [8] running maxima, [8] 1 / weight scale
+  float* const tmax = dpart + 8 * 128;                                        // [8] tile maxima, [8] running maxima, [8] weight scales
   float* const lmax = tmax + 8;
   float* const swl = lmax + 8;
-  float* const bl = swl + 16;                                                 // [8][256] biases, [256] density weights (epilogue operands: no global load, no vmcnt wait there)
+  float* const bl = swl + 16;                                                 // [8][256] biases, [256] density weights, density bias (epilogue operands: no global load, no vmcnt wait there)
   const int R = min(count[0], rcap);
   const int ntiles = (R + 127) / 128;
   if ((int)blockIdx.x >= ntiles) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  const float enc_max = T.mx[T.mx_enc];
-  const float sE = pp_split_scale(enc_max);
-  if (tid < 8) { tmax[tid] = 0.f; lmax[tid] = 0.f; swl[tid] = pp_split_scale(T.mx[T.mx_w0 + tid]); }
-  if (tid == 0) bl[9 * 256] = T.bd ? T.bd[0] : 0.f;
-  for (int i = tid; i < 9 * 256; i += 512) bl[i] = i < 2048 ? T.bias[i >> 8][i & 255] : (T.wd ? T.wd[i & 255] : 0.f);
+  const float in_max = T.mx[T.mx_in];
+  const float sE = pp_split_scale(in_max);
+  if (tid < 8) { tmax[tid] = 0.f; lmax[tid] = 0.f; swl[tid] = pp_split_scale(T.mx[T.mx_w[tid]]); }
+  if (tid == 0) bl[9 * 256] = (!BWD && T.bd) ? T.bd[0] : 0.f;
+  for (int i = tid; i < 9 * 256; i += 512) bl[i] = i < 2048 ? (BWD ? 0.f : T.bias[i >> 8][i & 255]) : (T.wd ? T.wd[i & 255] : 0.f);
 
   // weight stream: this lane's 16 bytes of the four 1 KB pieces of a step; gs = the next step to fetch
   const unsigned char* const wbase = T.wstream + w * 4096 + lane * 16;
@@ -143,7 +168,7 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const in
 #define TR_WLOAD(wb)                                                                                      \
   do {                                                                                                    \
     const unsigned char* p_ = wbase + (size_t)gs * TR_WSTEP;                                              \
-    if (!(TR_DBG & 8) || first_)                                                                           \
+    if (!(TR_DBG & 8) || first_)                                                                          \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) (wb)[i_] = *reinterpret_cast<const pp_half8*>(p_ + i_ * 1024); \
     gs = gs + 1 == TR_STEPS ? 0 : gs + 1;                                                                 \
   } while (0)
@@ -152,17 +177,16 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const in
   TR_WLOAD(wb1);
   first_ = false;
 
-  // encoded points of a tile: thread -> row tid / 4, eight columns at 8 (tid & 3) of both 32-wide chunks
+  // streamed input of a tile: thread -> row tid / 4, eight columns at 8 (tid & 3) of a 32-wide chunk; pe holds two chunks
   float4 pe[4];
-#define TR_ELOAD(tile_)                                                                                   \
+#define TR_ELOAD1(slot_, tile_, chunk_)                                                                   \
   do {                                                                                                    \
     const int row_ = min((tile_) * 128 + (tid >> 2), R - 1);                                              \
-    const float* p_ = T.enc + (size_t)row_ * 64 + (tid & 3) * 8;                                          \
-    pe[0] = *reinterpret_cast<const float4*>(p_);                                                         \
-    pe[1] = *reinterpret_cast<const float4*>(p_ + 4);                                                     \
-    pe[2] = *reinterpret_cast<const float4*>(p_ + 32);                                                    \
-    pe[3] = *reinterpret_cast<const float4*>(p_ + 36);                                                    \
+    const float* p_ = T.in + (size_t)row_ * T.in_ld + (chunk_) * 32 + (tid & 3) * 8;                      \
+    pe[2 * (slot_)] = *reinterpret_cast<const float4*>(p_);                                               \
+    pe[2 * (slot_) + 1] = *reinterpret_cast<const float4*>(p_ + 4);                                       \
   } while (0)
+#define TR_ELOAD(tile_) do { TR_ELOAD1(0, tile_, 0); TR_ELOAD1(1, tile_, 1); } while (0)
 #define TR_ECONV(c_, s_)                                                                                  \
   do {                                                                                                    \
     const float v_[8] = {pe[2 * (c_)].x, pe[2 * (c_)].y, pe[2 * (c_)].z, pe[2 * (c_)].w,                  \
@@ -177,34 +201,60 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const in
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int r0 = tile * 128;
-    float sA = sE;                                      // scale of the current layer's input
+    float sA = sE;                                      // scale of the current stage's input
     for (int l = 0; l < 8; ++l) {
       f32x16 acc[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-      if (l == 0 || l == 4) {                           // the encoded-point columns, one chunk at a time through E
+      if (l == 0 || (!BWD && l == 4)) {                 // the streamed columns, one chunk at a time through E
         TR_ECONV(0, sA);
+        if (BWD) TR_ELOAD1(0, tile, 2);
         TR_BARRIER();
         tr_step(E, wb0, acc, l31, lh);
         TR_WLOAD(wb0);
         TR_BARRIER();
         TR_ECONV(1, sA);
+        if (BWD) TR_ELOAD1(1, tile, 3);
         TR_BARRIER();
         tr_step(E, wb1, acc, l31, lh);
         TR_WLOAD(wb1);
         TR_BARRIER();
+        if (BWD) {
+          TR_ECONV(0, sA);
+          TR_BARRIER();
+          tr_step(E, wb0, acc, l31, lh);
+          TR_WLOAD(wb0);
+          TR_BARRIER();
+          TR_ECONV(1, sA);
+          TR_BARRIER();
+          tr_step(E, wb1, acc, l31, lh);
+          TR_WLOAD(wb1);
+          TR_BARRIER();
+        }
       }
-      if (l == 3) TR_ELOAD(tile);                       // for layer 4 of this tile
-      if (l == 7) TR_ELOAD(tile + (int)gridDim.x);      // for layer 0 of the next one (rows are clamped)
+      if (!BWD && l == 3) TR_ELOAD(tile);               // for layer 4 of this tile
+      if (l == 7) TR_ELOAD(tile + (int)gridDim.x);      // for stage 0 of the next one (rows are clamped)
+      // backward: the epilogue's per-row operands, fetched before the resident chunks so that their latency is long over
+      // (d raw of the tile's rows waits in LDS - dpart is otherwise unused in the backward chain - from stage 0 to the epilogue of stage 1)
+      unsigned mword[4] = {0u, 0u, 0u, 0u};
+      if (BWD) {
+        const uint16_t* __restrict__ br = T.bitsr[l];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = r0 + t * 32 + l31;            // (the mask planes are padded to whole tiles)
+          mword[t] = br[((size_t)row * 8 + w) * 2 + lh];
+        }
+        if (l == 0 && tid < 128) dpart[tid] = T.draw[(size_t)min(r0 + tid, R - 1) * T.draw_ld];
+      }
       if (l > 0) {
         // eight resident chunks, fully unrolled (a rolled loop makes the weight registers loop-carried: the compiler then loads
         // into temporaries and copies them at the latch behind a vmcnt(0), i.e. no prefetch at all).  Behind each chunk's
-        // matrix instructions the wavefront also sends 16 rows of that chunk - the PREVIOUS layer's output - to HBM from the
+        // matrix instructions the wavefront also sends 16 rows of that chunk - the PREVIOUS stage's output - to HBM from the
         // image: x = (hi + lo) / s, exactly the operand the matrix instructions consume (22 significant bits), as 128-byte
-        // rows; the write traffic is thereby spread evenly over the kernel instead of arriving in one burst per layer that
-        // every later weight fetch would have to wait behind (vmcnt retires in order).
+        // rows; the write traffic is thereby spread evenly over the kernel instead of arriving in one burst per stage that
+        // every later weight fetch would have to wait behind (vmcnt retires in order): 712 -> 553 us.
         float* __restrict__ outp = T.out[l - 1];
         const int ldp = T.ld[l - 1];
         const float invs = 1.0f / sA;
@@ -218,81 +268,103 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const in
           if (!(TR_DBG & 2)) {
             const pp_half8 h = *reinterpret_cast<const pp_half8*>(Img + kc * PL_A_BYTES + pl_slot_off(drow, dc8));
             const pp_half8 lo = *reinterpret_cast<const pp_half8*>(Img + kc * PL_A_BYTES + pl_slot_off(drow, 4 + dc8));
-            float4 a, b;
+            typedef float tr_f4 __attribute__((ext_vector_type(4)));
+            tr_f4 a, b;
             a.x = ((float)h[0] + (float)lo[0]) * invs; a.y = ((float)h[1] + (float)lo[1]) * invs;
             a.z = ((float)h[2] + (float)lo[2]) * invs; a.w = ((float)h[3] + (float)lo[3]) * invs;
             b.x = ((float)h[4] + (float)lo[4]) * invs; b.y = ((float)h[5] + (float)lo[5]) * invs;
             b.z = ((float)h[6] + (float)lo[6]) * invs; b.w = ((float)h[7] + (float)lo[7]) * invs;
             if (dok) {
               if (TR_NT) {
-                typedef float tr_f4 __attribute__((ext_vector_type(4)));
-                const tr_f4 a4 = {a.x, a.y, a.z, a.w}, b4 = {b.x, b.y, b.z, b.w};
-                __builtin_nontemporal_store(a4, reinterpret_cast<tr_f4*>(dptr + 32 * kc));
-                __builtin_nontemporal_store(b4, reinterpret_cast<tr_f4*>(dptr + 32 * kc + 4));
+                __builtin_nontemporal_store(a, reinterpret_cast<tr_f4*>(dptr + 32 * kc));
+                __builtin_nontemporal_store(b, reinterpret_cast<tr_f4*>(dptr + 32 * kc + 4));
               } else {
-                *reinterpret_cast<float4*>(dptr + 32 * kc) = a;
-                *reinterpret_cast<float4*>(dptr + 32 * kc + 4) = b;
+                *reinterpret_cast<tr_f4*>(dptr + 32 * kc) = a;
+                *reinterpret_cast<tr_f4*>(dptr + 32 * kc + 4) = b;
               }
             }
           }
         }
       }
-      // ---- epilogue: bias, ReLU, output to HBM, masks, tile maximum
+      // ---- epilogue.  forward: bias, ReLU, masks; backward: mask (+ the density term); then the tile maximum
       const float inv = 1.0f / (sA * swl[l]);
       const float* const bias = bl + l * 256 + 32 * w + 4 * lh;
+      const float* const wdl = bl + 2048 + 32 * w + 4 * lh;
       float* __restrict__ out = T.out[l];
       const int ld = T.ld[l];
       float vmax = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 b = *reinterpret_cast<const float4*>(bias + 8 * q);
+        const float4 b = *reinterpret_cast<const float4*>((BWD ? wdl : bias) + 8 * q);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           float4 v;
-          v.x = fmaxf(acc[t][4 * q] * inv + b.x, 0.f);
-          v.y = fmaxf(acc[t][4 * q + 1] * inv + b.y, 0.f);
-          v.z = fmaxf(acc[t][4 * q + 2] * inv + b.z, 0.f);
-          v.w = fmaxf(acc[t][4 * q + 3] * inv + b.w, 0.f);
+          if (BWD) {
+            const float d = l == 1 ? dpart[t * 32 + l31] : 0.f;
+            v.x = acc[t][4 * q] * inv + d * b.x;
+            v.y = acc[t][4 * q + 1] * inv + d * b.y;
+            v.z = acc[t][4 * q + 2] * inv + d * b.z;
+            v.w = acc[t][4 * q + 3] * inv + d * b.w;
+            const unsigned m = mword[t] >> (4 * q);
+            v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+            vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+          } else {
+            v.x = fmaxf(acc[t][4 * q] * inv + b.x, 0.f);
+            v.y = fmaxf(acc[t][4 * q + 1] * inv + b.y, 0.f);
+            v.z = fmaxf(acc[t][4 * q + 2] * inv + b.z, 0.f);
+            v.w = fmaxf(acc[t][4 * q + 3] * inv + b.w, 0.f);
+            vmax = fmaxf(vmax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+          }
           acc[t][4 * q] = v.x; acc[t][4 * q + 1] = v.y; acc[t][4 * q + 2] = v.z; acc[t][4 * q + 3] = v.w;
-          vmax = fmaxf(vmax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
           const int row = r0 + t * 32 + l31;
-          if (l == 7 && row < R && (!(TR_DBG & 2) || v.x == 123.456f)) *reinterpret_cast<float4*>(out + (size_t)row * ld + 32 * w + 8 * q + 4 * lh) = v;   // (layers 0 .. 6 leave through the image)
+          if (l == 7 && row < R && (!(TR_DBG & 2) || v.x == 123.456f)) *reinterpret_cast<float4*>(out + (size_t)row * ld + 32 * w + 8 * q + 4 * lh) = v;   // (stages 0 .. 6 leave through the image)
         }
       }
-      if (!(TR_DBG & 4)) {
-        uint32_t* __restrict__ bits = T.bits[l];
+      if (!BWD && !(TR_DBG & 4)) {
+        if (MROW) {
+          uint16_t* __restrict__ br = T.bitsr[l];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          // lane c of rm <- the 32 row bits of column c: the 64-lane compare mask of accumulator register j is rows 0..31 of
-          // column (j & 3) + 8 (j >> 2) in its low word and of that column + 4 in its high word
-          unsigned rm = 0u;
+          for (int t = 0; t < 4; ++t) {
+            unsigned m = 0u;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const unsigned long long bal = __ballot(acc[t][j] > 0.f);
-            const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
-            TR_WRITELANE(rm, blo, (j & 3) + 8 * (j >> 2));
-            TR_WRITELANE(rm, bhi, (j & 3) + 8 * (j >> 2) + 4);
+            for (int j = 0; j < 16; ++j) m |= (acc[t][j] > 0.f ? 1u : 0u) << j;     // bit j <-> accumulator register j of the lane
+            const int row = r0 + t * 32 + l31;
+            if (row < R) br[((size_t)row * 8 + w) * 2 + lh] = (uint16_t)m;
           }
-          // word of row half h' of a column = nibbles h', h' + 2, h' + 4, h' + 6 of its row bits; all 32 columns at once
-          unsigned e = rm & 0x0F0F0F0Fu, o = (rm >> 4) & 0x0F0F0F0Fu;
-          e = (e | (e >> 4)) & 0x00FF00FFu;
-          o = (o | (o >> 4)) & 0x00FF00FFu;
-          e = (e | (e >> 8)) & 0x0000FFFFu;
-          o = (o | (o >> 8)) & 0x0000FFFFu;
-          if (lane < 32) bits[((size_t)(r0 >> 5) + t) * 256 + 32 * w + lane] = e | (o << 16);
+        } else {
+          uint32_t* __restrict__ bits = T.bits[l];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            // lane c of rm <- the 32 row bits of column c: the 64-lane compare mask of accumulator register j is rows 0..31 of
+            // column (j & 3) + 8 (j >> 2) in its low word and of that column + 4 in its high word
+            unsigned rm = 0u;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const unsigned long long bal = __ballot(acc[t][j] > 0.f);
+              const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
+              TR_WRITELANE(rm, blo, (j & 3) + 8 * (j >> 2));
+              TR_WRITELANE(rm, bhi, (j & 3) + 8 * (j >> 2) + 4);
+            }
+            // word of row half h' of a column = nibbles h', h' + 2, h' + 4, h' + 6 of its row bits; all 32 columns at once
+            unsigned e = rm & 0x0F0F0F0Fu, o = (rm >> 4) & 0x0F0F0F0Fu;
+            e = (e | (e >> 4)) & 0x00FF00FFu;
+            o = (o | (o >> 4)) & 0x00FF00FFu;
+            e = (e | (e >> 8)) & 0x0000FFFFu;
+            o = (o | (o >> 8)) & 0x0000FFFFu;
+            if (lane < 32) bits[((size_t)(r0 >> 5) + t) * 256 + 32 * w + lane] = e | (o << 16);
+          }
         }
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
       if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(tmax + l), __float_as_uint(vmax));
-      if (tid == 0) tmax[(l + 7) & 7] = 0.f;            // the slot of the layer before: read long ago, next written a tile from now
-      const bool dens = l == 6 && T.wd;
+      if (tid == 0) tmax[(l + 7) & 7] = 0.f;            // the slot of the stage before: read long ago, next written a tile from now
+      const bool dens = !BWD && l == 6 && T.wd;
       if (dens) {
-        const float* const wd = bl + 2048 + 32 * w + 4 * lh;
         float p[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 c = *reinterpret_cast<const float4*>(wd + 8 * q);
+          const float4 c = *reinterpret_cast<const float4*>(wdl + 8 * q);
 #pragma unroll
           for (int t = 0; t < 4; ++t)
             p[t] += acc[t][4 * q] * c.x + acc[t][4 * q + 1] * c.y + acc[t][4 * q + 2] * c.z + acc[t][4 * q + 3] * c.w;
@@ -313,7 +385,7 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const in
         if (r0 + tid < R) { T.raw[r0 + tid] = s; T.density[r0 + tid] = s > 20.f ? s : log1pf(expf(s)); }
       }
       if (l < 7) {
-        sA = pp_split_scale(l == 3 ? fmaxf(tm, enc_max) : tm);      // layer 4 reads the encoded points at the same scale
+        sA = pp_split_scale((!BWD && l == 3) ? fmaxf(tm, in_max) : tm);     // layer 4 reads the encoded points at the same scale
         unsigned char* const chunk = Img + w * PL_A_BYTES;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -326,11 +398,12 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk_fwd(TrunkArgs T, const in
             *reinterpret_cast<pp_half4*>(chunk + pl_slot_off(row, 4 + q) + 8 * lh) = lo;
           }
       }
-      TR_BARRIER();                                     // B: the next layer's image is complete
+      TR_BARRIER();                                     // B: the next stage's image is complete
     }
   }
-  if (tid < 8) atomicMax(reinterpret_cast<unsigned int*>(T.mx + T.mx_a0 + tid), __float_as_uint(lmax[tid]));
+  if (tid < 8) atomicMax(reinterpret_cast<unsigned int*>(T.mx + T.mx_out[tid]), __float_as_uint(lmax[tid]));
 #undef TR_WLOAD
 #undef TR_ELOAD
+#undef TR_ELOAD1
 #undef TR_ECONV
 }

@@ -711,19 +711,22 @@ def test_scene_kernels_stay_inside_their_buffers(nerf_split):
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize('R,S', [(1023, 128), (37, 50), (1, 2)])
-def test_scene_trunk_kernel_equals_layer_by_layer_path(R, S):
+@pytest.mark.parametrize('R,S,chain', [(1023, 128, 3), (1023, 128, 1), (37, 50, 3), (37, 50, 1), (1, 2, 3)])
+def test_scene_trunk_kernel_equals_layer_by_layer_path(R, S, chain):
     """Option nerf_chain (csrc/pp_nerf_trunk.h: the eight feature layers + density head as one kernel, tile resident in LDS)
     against the layer-by-layer GEMMs on the same inputs: every stored activation, the raw density and the sample outputs
     agree to fp32 rounding of a 256..320-term sum (the two paths scale their fp16 operand pairs by different powers of two -
     tile maximum vs tensor maximum - so they are not bit-identical), the one-bit ReLU masks the data-gradient kernels read
     agree wherever the activations of both paths have the same state (and ARE that state), and the tensor maxima recorded
-    for the backward pass agree.  Sizes: four tiles per work-group, a ragged last tile, less than one tile."""
+    for the backward pass agree.  Sizes: four tiles per work-group, a ragged last tile, less than one tile.  chain = 1: fused
+    forward writing the masks in the layer-by-layer layout; chain = 3: in the fused chains' own layout ([row][wavefront][lane
+    half], bit j <-> column 32 w + 4 half + (j & 3) + 8 (j >> 2)), followed by a backward pass of both paths on the same
+    upstream gradients (parameter, centre and ray gradients)."""
     from poseprobe_amd import bg_nerf, ops
     dev = 'cuda'
     opt = bg_nerf.default_options(sample_intvs=S)
     torch.manual_seed(5)
-    nets = [bg_nerf.NeRF(opt, device=dev, options={'nerf_chain': c}) for c in (1, 0)]
+    nets = [bg_nerf.NeRF(opt, device=dev, options={'nerf_chain': c}) for c in (chain, 0)]
     g = torch.Generator().manual_seed(R + S)
     with torch.no_grad():
         for lin in list(nets[0].mlp_feat) + list(nets[0].mlp_rgb):
@@ -736,7 +739,7 @@ def test_scene_trunk_kernel_equals_layer_by_layer_path(R, S):
     ray = torch.randn(R, 3, generator=g).to(dev)
     depth = ((torch.rand(R, S, generator=g) + torch.arange(S)) / S * 2.0 + 0.4).to(dev).contiguous()
     count = torch.tensor([M], dtype=torch.int32, device=dev)
-    n_acts, _ = ops.nerf_workspace(M, R)
+    n_acts, n_scr = ops.nerf_workspace(M, R)
     res = []
     for n in nets:
         acts = torch.zeros(n_acts, device=dev)
@@ -774,10 +777,52 @@ def test_scene_trunk_kernel_equals_layer_by_layer_path(R, S):
             out = torch.zeros(Mp // 32, 32, 256, dtype=torch.bool, device=dev)
             out[:, rows.reshape(-1), :] = bits.permute(0, 2, 3, 1).reshape(Mp // 32, 32, 256)
             return out.view(Mp, 256)[:M]
-        s1, s0 = states(b1), states(b0)
+        def states_rows(b):
+            wds = torch.stack([b & 0xFFFF, (b >> 16) & 0xFFFF], -1).view(Mp, 8, 2)                   # [row][w][half]
+            j = torch.arange(16, device=dev)
+            bits = ((wds[..., None] >> j) & 1).bool()                                                  # [row, w, half, j]
+            col = (32 * torch.arange(8, device=dev)[:, None, None] + 4 * torch.arange(2, device=dev)[None, :, None]
+                   + ((j & 3) + 8 * (j >> 2))[None, None, :]).reshape(-1)
+            out = torch.zeros(Mp, 256, dtype=torch.bool, device=dev)
+            out[:, col] = bits.reshape(Mp, 256)
+            return out[:M]
+        s1, s0 = (states_rows(b1) if chain == 3 else states(b1)), states(b0)
         x1, x0 = acts_l[l]
         assert torch.equal(s1, x1 > 0), f'layer {l}: mask bits of the fused kernel are not the states of its own activations'
         assert torch.equal(s0, x0 > 0)
         assert int((s1 != s0).sum()) <= max(2, 2e-6 * s1.numel()), f'layer {l}: {int((s1 != s0).sum())} states differ'
     assert_close(d1, d0, rtol=2e-5, scaled=2e-6, name='density')
     assert_close(rgb1, rgb0, rtol=0, atol=2e-6, name='rgb samples')
+    if chain != 3:
+        return
+    # backward of both paths on the SAME forward state: the fused forward's activation block, with its mask planes re-packed
+    # into the layer-by-layer layout for the layer-by-layer backward - identical ReLU states, so the gradients must agree
+    # to rounding (no allowance for flipped states)
+    def pack_cols(st):                                                # [M,256] bool -> int32 words of the layer-by-layer layout
+        full = torch.zeros(Mp, 256, dtype=torch.bool, device=dev)
+        full[:M] = st
+        j = torch.arange(16, device=dev)
+        rows = ((j & 3) + 8 * (j >> 2))[None, :] + 4 * torch.arange(2, device=dev)[:, None]          # [half, j]
+        x = full.view(Mp // 32, 32, 256)[:, rows.reshape(-1), :].view(Mp // 32, 2, 16, 256)          # [g, half, j, col]
+        wds = (x.to(torch.int64) << j[None, None, :, None]).sum(2)                                    # [g, half, col]
+        return (wds[:, 0] | (wds[:, 1] << 16)).to(torch.int64).view(-1)                              # [g * 256 + col]
+    a_conv = a1.clone()
+    off_b = M * (64 + sum(OUT_LD) + 128 + 1) + 64
+    for l in range(8):
+        words = pack_cols(states_rows(a1[off_b:off_b + Mp * 8].view(torch.int32)))
+        a_conv[off_b:off_b + Mp * 8] = ((words + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32).view(torch.float32)   # same 32 bits
+        off_b += Mp * 8
+    g_rgb = torch.randn(M, 3, generator=g).to(dev)
+    g_den = torch.randn(M, generator=g).to(dev)
+    grads = []
+    for n, acts in ((nets[0], a1), (nets[1], a_conv)):
+        scr = torch.zeros(n_scr, device=dev)
+        pg = torch.zeros_like(n.flat)
+        gc, gr = torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev)
+        ops.nerf_bwd(n.flat, ray, depth, count, R, S, acts, rgb1, g_rgb, g_den, scr, pg, gc, gr, n.ctx)
+        torch.cuda.synchronize()
+        grads.append((pg, gc, gr))
+    (pg1, gc1, gr1), (pg0, gc0, gr0) = grads
+    assert_close(pg1, pg0, rtol=2e-5, scaled=2e-5, name='parameter gradients')
+    assert_close(gc1, gc0, rtol=2e-5, scaled=2e-5, name='g_center')
+    assert_close(gr1, gr0, rtol=2e-5, scaled=2e-5, name='g_ray')

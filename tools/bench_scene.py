@@ -7,7 +7,7 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 opt = bg_nerf.default_options()
-chain = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+chain = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 net = bg_nerf.NeRF(opt, device='cuda', options={'nerf_chain': chain}); net.progress.data.fill_(0.6)
 eng = bg_nerf.SceneEngine(net, lr=1e-3)
 g = torch.Generator().manual_seed(0)
