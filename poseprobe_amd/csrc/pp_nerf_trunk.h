@@ -44,6 +44,18 @@
 #endif
 #define TR_WSTEP 32768                  // bytes of one step's weights: 256 columns x 32 k x (hi | lo) halfs
 
+#ifdef TR_TIMERS      // phase timers (experiments): wave 0 of every work-group sums s_memtime deltas per phase
+__device__ unsigned long long g_tr_t[16];
+extern "C" int pp_debug_read_trunk_timers(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tr_t), sizeof(g_tr_t)) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tr_t), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#define TR_TICK(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); tsum[i] += t__ - tprev; tprev = t__; } while (0)
+#else
+#define TR_TICK(i) do {} while (0)
+#endif
+
 struct TrunkArgs {
   const float* in;                      // what the chain reads from HBM: forward [M][64] encoded points, backward [M][128] d(hidden of the colour head)
   int in_ld;
@@ -198,6 +210,9 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
   } while (0)
   TR_ELOAD((int)blockIdx.x);
   TR_BARRIER();
+#ifdef TR_TIMERS
+  unsigned long long tsum[8] = {0}, tprev = __builtin_readcyclecounter();
+#endif
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int r0 = tile * 128;
@@ -208,6 +223,7 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+      TR_TICK(6);
       if (l == 0 || (!BWD && l == 4)) {                 // the streamed columns, one chunk at a time through E
         TR_ECONV(0, sA);
         if (BWD) TR_ELOAD1(0, tile, 2);
@@ -234,6 +250,7 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
           TR_BARRIER();
         }
       }
+      TR_TICK(0);
       if (!BWD && l == 3) TR_ELOAD(tile);               // for layer 4 of this tile
       if (l == 7) TR_ELOAD(tile + (int)gridDim.x);      // for stage 0 of the next one (rows are clamped)
       // backward: the epilogue's per-row operands, fetched before the resident chunks so that their latency is long over
@@ -286,6 +303,7 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
           }
         }
       }
+      TR_TICK(1);
       // ---- epilogue.  forward: bias, ReLU, masks; backward: mask (+ the density term); then the tile maximum
       const float inv = 1.0f / (sA * swl[l]);
       const float* const bias = bl + l * 256 + 32 * w + 4 * lh;
@@ -300,19 +318,24 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
         for (int t = 0; t < 4; ++t) {
           float4 v;
           if (BWD) {
+            // mask: bit -> all ones / zero by a signed bit-field extract, then AND on the value's bits (2 instructions per value)
             const float d = l == 1 ? dpart[t * 32 + l31] : 0.f;
-            v.x = acc[t][4 * q] * inv + d * b.x;
-            v.y = acc[t][4 * q + 1] * inv + d * b.y;
-            v.z = acc[t][4 * q + 2] * inv + d * b.z;
-            v.w = acc[t][4 * q + 3] * inv + d * b.w;
-            const unsigned m = mword[t] >> (4 * q);
-            v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+            const int mw = (int)mword[t];
+            v.x = __builtin_fmaf(d, b.x, acc[t][4 * q] * inv);
+            v.y = __builtin_fmaf(d, b.y, acc[t][4 * q + 1] * inv);
+            v.z = __builtin_fmaf(d, b.z, acc[t][4 * q + 2] * inv);
+            v.w = __builtin_fmaf(d, b.w, acc[t][4 * q + 3] * inv);
+            v.x = __uint_as_float(__float_as_uint(v.x) & (unsigned)__builtin_amdgcn_sbfe(mw, 4 * q, 1));
+            v.y = __uint_as_float(__float_as_uint(v.y) & (unsigned)__builtin_amdgcn_sbfe(mw, 4 * q + 1, 1));
+            v.z = __uint_as_float(__float_as_uint(v.z) & (unsigned)__builtin_amdgcn_sbfe(mw, 4 * q + 2, 1));
+            v.w = __uint_as_float(__float_as_uint(v.w) & (unsigned)__builtin_amdgcn_sbfe(mw, 4 * q + 3, 1));
             vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
           } else {
-            v.x = fmaxf(acc[t][4 * q] * inv + b.x, 0.f);
-            v.y = fmaxf(acc[t][4 * q + 1] * inv + b.y, 0.f);
-            v.z = fmaxf(acc[t][4 * q + 2] * inv + b.z, 0.f);
-            v.w = fmaxf(acc[t][4 * q + 3] * inv + b.w, 0.f);
+            // (the product with the power of two is exact, so the fused multiply-add rounds exactly as multiply, add would)
+            v.x = fmaxf(__builtin_fmaf(acc[t][4 * q], inv, b.x), 0.f);
+            v.y = fmaxf(__builtin_fmaf(acc[t][4 * q + 1], inv, b.y), 0.f);
+            v.z = fmaxf(__builtin_fmaf(acc[t][4 * q + 2], inv, b.z), 0.f);
+            v.w = fmaxf(__builtin_fmaf(acc[t][4 * q + 3], inv, b.w), 0.f);
             vmax = fmaxf(vmax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
           }
           acc[t][4 * q] = v.x; acc[t][4 * q + 1] = v.y; acc[t][4 * q + 2] = v.z; acc[t][4 * q + 3] = v.w;
@@ -325,9 +348,11 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
           uint16_t* __restrict__ br = T.bitsr[l];
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
+            // bit j <-> accumulator register j of the lane.  The values are ReLU outputs (+0 or positive): bits + 0x7FFFFFFF
+            // carries into bit 31 exactly for the positive ones, and v_alignbit shifts that bit into the word - 2 instructions per value
             unsigned m = 0u;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) m |= (acc[t][j] > 0.f ? 1u : 0u) << j;     // bit j <-> accumulator register j of the lane
+            for (int j = 15; j >= 0; --j) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[t][j]) + 0x7FFFFFFFu, 31);
             const int row = r0 + t * 32 + l31;
             if (row < R) br[((size_t)row * 8 + w) * 2 + lh] = (uint16_t)m;
           }
@@ -355,9 +380,16 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
           }
         }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-      if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(tmax + l), __float_as_uint(vmax));
+      // maximum of each row of 16 lanes by four DPP moves (no LDS round trips, unlike __shfl_xor), then four lanes per
+      // wavefront into the LDS slot (all 64 lanes on one address measured far slower: +120 k ticks per work-group)
+      {
+        int vi = (int)__float_as_uint(vmax);              // non-negative floats order as integers
+        vi = max(vi, __builtin_amdgcn_mov_dpp(vi, 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+        vi = max(vi, __builtin_amdgcn_mov_dpp(vi, 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+        vi = max(vi, __builtin_amdgcn_mov_dpp(vi, 0x141, 0xF, 0xF, true));    // row_half_mirror
+        vi = max(vi, __builtin_amdgcn_mov_dpp(vi, 0x140, 0xF, 0xF, true));    // row_mirror
+        if ((lane & 15) == 0) atomicMax(reinterpret_cast<unsigned int*>(tmax + l), (unsigned)vi);
+      }
       if (tid == 0) tmax[(l + 7) & 7] = 0.f;            // the slot of the stage before: read long ago, next written a tile from now
       const bool dens = !BWD && l == 6 && T.wd;
       if (dens) {
@@ -375,7 +407,9 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
           if (lh == 0) dpart[w * 128 + t * 32 + l31] = p[t];
         }
       }
+      TR_TICK(2);
       TR_BARRIER();                                     // A: every wavefront is done with the image; maximum and partials complete
+      TR_TICK(3);
       const float tm = tmax[l];
       if (tid == 0) lmax[l] = fmaxf(lmax[l], tm);
       if (dens && tid < 128) {
@@ -398,10 +432,16 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
             *reinterpret_cast<pp_half4*>(chunk + pl_slot_off(row, 4 + q) + 8 * lh) = lo;
           }
       }
+      TR_TICK(4);
       TR_BARRIER();                                     // B: the next stage's image is complete
+      TR_TICK(5);
     }
   }
   if (tid < 8) atomicMax(reinterpret_cast<unsigned int*>(T.mx + T.mx_out[tid]), __float_as_uint(lmax[tid]));
+#ifdef TR_TIMERS
+  if (tid == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_tr_t[(BWD ? 8 : 0) + i], tsum[i]);
+#endif
 #undef TR_WLOAD
 #undef TR_ELOAD
 #undef TR_ELOAD1
