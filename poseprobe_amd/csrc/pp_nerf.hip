@@ -678,6 +678,9 @@ static int nerf_wide_tiles() { return pp_opt(PP_OPT_NERF_BN) == 256; }
 //                      fused kernels' own layout, so both passes of a step must see the same value
 #define NERF_CHAIN ((pp_opt(PP_OPT_NERF_CHAIN) & 1) && NERF_PLANES)
 #define NERF_CHAIN_BWD (pp_opt(PP_OPT_NERF_CHAIN) == 3 && NERF_PLANES)
+//   nerf_chain_nw      wavefronts per work-group of the fused chains: 8 = one work-group on a 128-sample tile per CU, 4 = two work-groups on
+//                      64-sample tiles per CU (one's epilogue beside the other's matrix instructions; twice the weight traffic from L2)
+#define NERF_CHAIN_NW pp_opt(PP_OPT_NERF_CHAIN_NW)
 
 template <int EPI>
 static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, int K, int Nout, const float* bias,
@@ -798,9 +801,16 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
     T.wstream = reinterpret_cast<const unsigned char*>(A.wimg[0]);
     T.wd = params + L.wd; T.bd = params + L.bd; T.raw = A.raw; T.density = density_samples;
     T.mx = mx; T.mx_in = MX_ENC;
-    const int tiles = pp_div_up(M, 128), cus = pp_num_cus();
-    if (NERF_CHAIN_BWD) hipLaunchKernelGGL((k_nerf_trunk<false, true>), dim3(tiles < cus ? tiles : cus), dim3(512), 0, st, T, count, M);
-    else hipLaunchKernelGGL((k_nerf_trunk<false, false>), dim3(tiles < cus ? tiles : cus), dim3(512), 0, st, T, count, M);
+    const int cus = pp_num_cus();
+    if (NERF_CHAIN_NW == 4) {                       // 64-row tiles, two work-groups per CU
+      const int tiles = pp_div_up(M, 64), grid = tiles < 2 * cus ? tiles : 2 * cus;
+      if (NERF_CHAIN_BWD) hipLaunchKernelGGL((k_nerf_trunk<false, true, 4>), dim3(grid), dim3(256), 0, st, T, count, M);
+      else hipLaunchKernelGGL((k_nerf_trunk<false, false, 4>), dim3(grid), dim3(256), 0, st, T, count, M);
+    } else {
+      const int tiles = pp_div_up(M, 128), grid = tiles < cus ? tiles : cus;
+      if (NERF_CHAIN_BWD) hipLaunchKernelGGL((k_nerf_trunk<false, true, 8>), dim3(grid), dim3(512), 0, st, T, count, M);
+      else hipLaunchKernelGGL((k_nerf_trunk<false, false, 8>), dim3(grid), dim3(512), 0, st, T, count, M);
+    }
   } else {
     const float* in = A.enc;
     for (int l = 0; l < 8; ++l) {
@@ -917,8 +927,14 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
     T.wstream = reinterpret_cast<const unsigned char*>(r0t_img);
     T.wd = params + L.wd; T.draw = P + 256; T.draw_ld = 288;
     T.mx = mx; T.mx_in = MX_DH;
-    const int tiles = pp_div_up(M, 128), cus = pp_num_cus();
-    hipLaunchKernelGGL((k_nerf_trunk<true, false>), dim3(tiles < cus ? tiles : cus), dim3(512), 0, st, T, count, M);
+    const int cus = pp_num_cus();
+    if (NERF_CHAIN_NW == 4) {
+      const int tiles = pp_div_up(M, 64);
+      hipLaunchKernelGGL((k_nerf_trunk<true, true, 4>), dim3(tiles < 2 * cus ? tiles : 2 * cus), dim3(256), 0, st, T, count, M);
+    } else {
+      const int tiles = pp_div_up(M, 128);
+      hipLaunchKernelGGL((k_nerf_trunk<true, true, 8>), dim3(tiles < cus ? tiles : cus), dim3(512), 0, st, T, count, M);
+    }
     nerf_gemm_tn(st, P, 288, 256, A.a[6], 256, 256, params_grad + L.w[7], params_grad + L.b[7], count, M, slot(MX_P), slot(MX_A0 + 6));
     for (int l = 6; l >= 1; --l)
       nerf_gemm_tn(st, DY[l], 256, 256, A.a[l - 1], NERF_OUT_LD[l - 1], NERF_IN_LD[l], params_grad + L.w[l], params_grad + L.b[l], count, M,

@@ -115,30 +115,38 @@ static __global__ __launch_bounds__(256) void k_pack_trunk(TrunkPackJobs J, cons
   *reinterpret_cast<pp_half8*>(q + 1024) = lo;
 }
 
-// one K-chunk: 24 matrix instructions per wavefront on the chunk image `img` and the weight registers wb = {hi, lo} x 2 halves
-__device__ __forceinline__ void tr_step(const unsigned char* img, const pp_half8 (&wb)[4], f32x16 (&acc)[4], int l31, int lh) {
+// one K-chunk: TM x TU x 6 matrix instructions per wavefront on the chunk image `img` (TM blocks of 32 rows, `rb` bytes apart)
+// and the weight registers wb = TU column blocks x 2 halves x {hi, lo}
+template <int TM, int TU>
+__device__ __forceinline__ void tr_step(const unsigned char* img, const pp_half8 (&wb)[TU * 4], f32x16 (&acc)[TM][TU], int l31, int lh) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    pp_half8 ah[4], al[4];
+    pp_half8 ah[TM], al[TM];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < TM; ++t) {
       const int row = t * 32 + l31;
-      if (TR_DBG & 16) { ah[t] = wb[t]; al[t] = wb[3 - t]; continue; }
+      if (TR_DBG & 16) { ah[t] = wb[t & 3]; al[t] = wb[3 - (t & 3)]; continue; }
       ah[t] = *reinterpret_cast<const pp_half8*>(img + pl_slot_off(row, ks * 2 + lh));
       al[t] = *reinterpret_cast<const pp_half8*>(img + pl_slot_off(row, 4 + ks * 2 + lh));
     }
     if (TR_DBG & 1) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t][ks] += (float)ah[t][0] + (float)al[t][1] + (float)wb[ks * 2][2] + (float)wb[ks * 2 + 1][3];
+      for (int t = 0; t < TM; ++t) acc[t][0][ks] += (float)ah[t][0] + (float)al[t][1] + (float)wb[ks * 2][2] + (float)wb[ks * 2 + 1][3];
       continue;
     }
-    // small terms first; the three products of one block are four instructions apart
+    // small terms first; the three products of one block are TM x TU instructions apart
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks * 2 + 1], ah[t], acc[t], 0, 0, 0);
+    for (int u = 0; u < TU; ++u)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks * 2], al[t], acc[t], 0, 0, 0);
+      for (int t = 0; t < TM; ++t) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[u * 4 + ks * 2 + 1], ah[t], acc[t][u], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks * 2], ah[t], acc[t], 0, 0, 0);
+    for (int u = 0; u < TU; ++u)
+#pragma unroll
+      for (int t = 0; t < TM; ++t) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[u * 4 + ks * 2], al[t], acc[t][u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+#pragma unroll
+      for (int t = 0; t < TM; ++t) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[u * 4 + ks * 2], ah[t], acc[t][u], 0, 0, 0);
   }
 }
 
@@ -151,18 +159,32 @@ __device__ __forceinline__ void tr_step(const unsigned char* img, const pp_half8
 // BWD = false: stages = layers 0 .. 7 (bias, ReLU, masks out, density head at layer 6), streamed chunks: 2 in front of layers 0 and 4
 // BWD = true:  stage 0 = d(layer 7) from d(hidden) through R0 (4 streamed chunks), stage s = d(layer 7 - s) through W_{8 - s};
 //              epilogue = the mask of the stage's output (+ the density term at stage 1)
-template <bool BWD, bool MROW>
-__global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_t* __restrict__ count, int rcap) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[TR_IMG_BYTES + PL_A_BYTES + 8 * 128 * 4 + 128 + 9 * 1024 + 64];
+// NW = 8: eight wavefronts on a 128-row tile, one work-group per CU (wavefront w: column block w, all four 32-row blocks);
+// NW = 4: four wavefronts on a 64-row tile, TWO work-groups per CU (wavefront w: column blocks 2 w and 2 w + 1, two row blocks).
+//         Every output element costs ~10 vector instructions of epilogue (scale, bias, ReLU, mask bit, split into hi / lo) against
+//         768 multiply-adds on the matrix pipe, so with both wavefronts of a SIMD in the same work-group - in the epilogue at
+//         the same time, behind the same barriers - the matrix pipe idles for 45 % of a stage (phase timers: 12.4 k ticks of
+//         steps, 11.5 k of epilogue + conversion per stage and tile).  Two independent work-groups per CU drift apart, so one
+//         wavefront's epilogue runs beside the other's matrix instructions; the price is that each streams the weights for half
+//         as many rows (2 x the L2 -> CU weight traffic).
+template <bool BWD, bool MROW, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_nerf_trunk(TrunkArgs T, const int32_t* __restrict__ count, int rcap) {
+  constexpr int TM = NW / 2;            // 32-row blocks of a tile
+  constexpr int TU = 8 / NW;            // 32-column blocks of a wavefront
+  constexpr int TR = 32 * TM;           // rows of a tile
+  constexpr int CH = TR * 128;          // bytes of one chunk image
+  constexpr int NT = NW * 64;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * CH + CH + 8 * TR * 4 + 128 + 3 * 1024 + 64];
   unsigned char* const Img = smem;
-  unsigned char* const E = smem + TR_IMG_BYTES;
-  float* const dpart = reinterpret_cast<float*>(E + PL_A_BYTES);             // [8 wavefronts][128 rows]
-  float* const tmax = dpart + 8 * 128;                                        // [8] tile maxima, [8] running maxima, [8] weight scales
+  unsigned char* const E = smem + 8 * CH;
+  float* const dpart = reinterpret_cast<float*>(E + CH);                      // [8 column blocks][TR rows]
+  float* const tmax = dpart + 8 * TR;                                         // [8] tile maxima, [8] running maxima, [8] weight scales
   float* const lmax = tmax + 8;
   float* const swl = lmax + 8;
-  float* const bl = swl + 16;                                                 // [8][256] biases, [256] density weights, density bias (epilogue operands: no global load, no vmcnt wait there)
+  float* const bl = swl + 16;                                                 // [2][256] bias of this / the next stage, [256] density weights, density bias
+  float* const wdl_ = bl + 512;                                               // (epilogue operands: no global load, no vmcnt wait there)
   const int R = min(count[0], rcap);
-  const int ntiles = (R + 127) / 128;
+  const int ntiles = (R + TR - 1) / TR;
   if ((int)blockIdx.x >= ntiles) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -170,18 +192,18 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
   const float in_max = T.mx[T.mx_in];
   const float sE = pp_split_scale(in_max);
   if (tid < 8) { tmax[tid] = 0.f; lmax[tid] = 0.f; swl[tid] = pp_split_scale(T.mx[T.mx_w[tid]]); }
-  if (tid == 0) bl[9 * 256] = (!BWD && T.bd) ? T.bd[0] : 0.f;
-  for (int i = tid; i < 9 * 256; i += 512) bl[i] = i < 2048 ? (BWD ? 0.f : T.bias[i >> 8][i & 255]) : (T.wd ? T.wd[i & 255] : 0.f);
+  if (tid == 0) wdl_[256] = (!BWD && T.bd) ? T.bd[0] : 0.f;
+  for (int i = tid; i < 256; i += NT) { wdl_[i] = T.wd ? T.wd[i] : 0.f; bl[i] = BWD ? 0.f : T.bias[0][i]; }
 
-  // weight stream: this lane's 16 bytes of the four 1 KB pieces of a step; gs = the next step to fetch
-  const unsigned char* const wbase = T.wstream + w * 4096 + lane * 16;
+  // weight stream: this lane's 16 bytes of the TU x four 1 KB pieces of a step; gs = the next step to fetch
+  const unsigned char* const wbase = T.wstream + (TU * w) * 4096 + lane * 16;
   int gs = 0;
-  pp_half8 wb0[4], wb1[4];
+  pp_half8 wb0[TU * 4], wb1[TU * 4];
 #define TR_WLOAD(wb)                                                                                      \
   do {                                                                                                    \
     const unsigned char* p_ = wbase + (size_t)gs * TR_WSTEP;                                              \
     if (!(TR_DBG & 8) || first_)                                                                          \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) (wb)[i_] = *reinterpret_cast<const pp_half8*>(p_ + i_ * 1024); \
+    _Pragma("unroll") for (int i_ = 0; i_ < TU * 4; ++i_) (wb)[i_] = *reinterpret_cast<const pp_half8*>(p_ + i_ * 1024); \
     gs = gs + 1 == TR_STEPS ? 0 : gs + 1;                                                                 \
   } while (0)
   bool first_ = true;
@@ -193,7 +215,7 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
   float4 pe[4];
 #define TR_ELOAD1(slot_, tile_, chunk_)                                                                   \
   do {                                                                                                    \
-    const int row_ = min((tile_) * 128 + (tid >> 2), R - 1);                                              \
+    const int row_ = min((tile_) * TR + (tid >> 2), R - 1);                                               \
     const float* p_ = T.in + (size_t)row_ * T.in_ld + (chunk_) * 32 + (tid & 3) * 8;                      \
     pe[2 * (slot_)] = *reinterpret_cast<const float4*>(p_);                                               \
     pe[2 * (slot_) + 1] = *reinterpret_cast<const float4*>(p_ + 4);                                       \
@@ -215,37 +237,42 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
 #endif
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int r0 = tile * 128;
+    const int r0 = tile * TR;
     float sA = sE;                                      // scale of the current stage's input
     for (int l = 0; l < 8; ++l) {
-      f32x16 acc[4];
+      f32x16 acc[TM][TU];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < TM; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        for (int u = 0; u < TU; ++u)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+      // forward: the next stage's bias on its way to LDS (fetched here, written behind barrier A, read a stage later)
+      float bnext = 0.f;
+      if (!BWD && tid < 256) bnext = T.bias[(l + 1) & 7][tid];
       TR_TICK(6);
       if (l == 0 || (!BWD && l == 4)) {                 // the streamed columns, one chunk at a time through E
         TR_ECONV(0, sA);
         if (BWD) TR_ELOAD1(0, tile, 2);
         TR_BARRIER();
-        tr_step(E, wb0, acc, l31, lh);
+        tr_step<TM, TU>(E, wb0, acc, l31, lh);
         TR_WLOAD(wb0);
         TR_BARRIER();
         TR_ECONV(1, sA);
         if (BWD) TR_ELOAD1(1, tile, 3);
         TR_BARRIER();
-        tr_step(E, wb1, acc, l31, lh);
+        tr_step<TM, TU>(E, wb1, acc, l31, lh);
         TR_WLOAD(wb1);
         TR_BARRIER();
         if (BWD) {
           TR_ECONV(0, sA);
           TR_BARRIER();
-          tr_step(E, wb0, acc, l31, lh);
+          tr_step<TM, TU>(E, wb0, acc, l31, lh);
           TR_WLOAD(wb0);
           TR_BARRIER();
           TR_ECONV(1, sA);
           TR_BARRIER();
-          tr_step(E, wb1, acc, l31, lh);
+          tr_step<TM, TU>(E, wb1, acc, l31, lh);
           TR_WLOAD(wb1);
           TR_BARRIER();
         }
@@ -255,15 +282,17 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
       if (l == 7) TR_ELOAD(tile + (int)gridDim.x);      // for stage 0 of the next one (rows are clamped)
       // backward: the epilogue's per-row operands, fetched before the resident chunks so that their latency is long over
       // (d raw of the tile's rows waits in LDS - dpart is otherwise unused in the backward chain - from stage 0 to the epilogue of stage 1)
-      unsigned mword[4] = {0u, 0u, 0u, 0u};
+      unsigned mword[TM][TU];
       if (BWD) {
         const uint16_t* __restrict__ br = T.bitsr[l];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int row = r0 + t * 32 + l31;            // (the mask planes are padded to whole tiles)
-          mword[t] = br[((size_t)row * 8 + w) * 2 + lh];
-        }
-        if (l == 0 && tid < 128) dpart[tid] = T.draw[(size_t)min(r0 + tid, R - 1) * T.draw_ld];
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TU; ++u) {
+            const int row = r0 + t * 32 + l31;          // (the mask planes are padded to whole 128-row tiles)
+            mword[t][u] = br[((size_t)row * 8 + TU * w + u) * 2 + lh];
+          }
+        if (l == 0 && tid < TR) dpart[tid] = T.draw[(size_t)min(r0 + tid, R - 1) * T.draw_ld];
       }
       if (l > 0) {
         // eight resident chunks, fully unrolled (a rolled loop makes the weight registers loop-carried: the compiler then loads
@@ -280,11 +309,11 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
         float* const dptr = outp + (size_t)(r0 + drow) * ldp + 8 * dc8;
 #pragma unroll
         for (int kc = 0; kc < 8; ++kc) {
-          if (kc & 1) { tr_step(Img + kc * PL_A_BYTES, wb1, acc, l31, lh); TR_WLOAD(wb1); }
-          else { tr_step(Img + kc * PL_A_BYTES, wb0, acc, l31, lh); TR_WLOAD(wb0); }
+          if (kc & 1) { tr_step<TM, TU>(Img + kc * CH, wb1, acc, l31, lh); TR_WLOAD(wb1); }
+          else { tr_step<TM, TU>(Img + kc * CH, wb0, acc, l31, lh); TR_WLOAD(wb0); }
           if (!(TR_DBG & 2)) {
-            const pp_half8 h = *reinterpret_cast<const pp_half8*>(Img + kc * PL_A_BYTES + pl_slot_off(drow, dc8));
-            const pp_half8 lo = *reinterpret_cast<const pp_half8*>(Img + kc * PL_A_BYTES + pl_slot_off(drow, 4 + dc8));
+            const pp_half8 h = *reinterpret_cast<const pp_half8*>(Img + kc * CH + pl_slot_off(drow, dc8));
+            const pp_half8 lo = *reinterpret_cast<const pp_half8*>(Img + kc * CH + pl_slot_off(drow, 4 + dc8));
             typedef float tr_f4 __attribute__((ext_vector_type(4)));
             tr_f4 a, b;
             a.x = ((float)h[0] + (float)lo[0]) * invs; a.y = ((float)h[1] + (float)lo[1]) * invs;
@@ -306,78 +335,86 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
       TR_TICK(1);
       // ---- epilogue.  forward: bias, ReLU, masks; backward: mask (+ the density term); then the tile maximum
       const float inv = 1.0f / (sA * swl[l]);
-      const float* const bias = bl + l * 256 + 32 * w + 4 * lh;
-      const float* const wdl = bl + 2048 + 32 * w + 4 * lh;
       float* __restrict__ out = T.out[l];
       const int ld = T.ld[l];
       float vmax = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 b = *reinterpret_cast<const float4*>((BWD ? wdl : bias) + 8 * q);
+      for (int u = 0; u < TU; ++u) {
+        const int cb = TU * w + u;                      // 32-column block of the stage's output = K-chunk of the next stage
+        const float* const bias = bl + (l & 1) * 256 + 32 * cb + 4 * lh;
+        const float* const wdl = wdl_ + 32 * cb + 4 * lh;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float4 v;
-          if (BWD) {
-            // mask: bit -> all ones / zero by a signed bit-field extract, then AND on the value's bits (2 instructions per value)
-            const float d = l == 1 ? dpart[t * 32 + l31] : 0.f;
-            const int mw = (int)mword[t];
-            v.x = __builtin_fmaf(d, b.x, acc[t][4 * q] * inv);
-            v.y = __builtin_fmaf(d, b.y, acc[t][4 * q + 1] * inv);
-            v.z = __builtin_fmaf(d, b.z, acc[t][4 * q + 2] * inv);
-            v.w = __builtin_fmaf(d, b.w, acc[t][4 * q + 3] * inv);
-            v.x = __uint_as_float(__float_as_uint(v.x) & (unsigned)__builtin_amdgcn_sbfe(mw, 4 * q, 1));
-            v.y = __uint_as_float(__float_as_uint(v.y) & (unsigned)__builtin_amdgcn_sbfe(mw, 4 * q + 1, 1));
-            v.z = __uint_as_float(__float_as_uint(v.z) & (unsigned)__builtin_amdgcn_sbfe(mw, 4 * q + 2, 1));
-            v.w = __uint_as_float(__float_as_uint(v.w) & (unsigned)__builtin_amdgcn_sbfe(mw, 4 * q + 3, 1));
-            vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-          } else {
-            // (the product with the power of two is exact, so the fused multiply-add rounds exactly as multiply, add would)
-            v.x = fmaxf(__builtin_fmaf(acc[t][4 * q], inv, b.x), 0.f);
-            v.y = fmaxf(__builtin_fmaf(acc[t][4 * q + 1], inv, b.y), 0.f);
-            v.z = fmaxf(__builtin_fmaf(acc[t][4 * q + 2], inv, b.z), 0.f);
-            v.w = fmaxf(__builtin_fmaf(acc[t][4 * q + 3], inv, b.w), 0.f);
-            vmax = fmaxf(vmax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        for (int q = 0; q < 4; ++q) {
+          const float4 b = *reinterpret_cast<const float4*>((BWD ? wdl : bias) + 8 * q);
+#pragma unroll
+          for (int t = 0; t < TM; ++t) {
+            float4 v;
+            if (BWD) {
+              // mask: bit -> all ones / zero by a signed bit-field extract, then AND on the value's bits (2 instructions per value)
+              const float d = l == 1 ? dpart[t * 32 + l31] : 0.f;
+              const int mw = (int)mword[t][u];
+              v.x = __builtin_fmaf(d, b.x, acc[t][u][4 * q] * inv);
+              v.y = __builtin_fmaf(d, b.y, acc[t][u][4 * q + 1] * inv);
+              v.z = __builtin_fmaf(d, b.z, acc[t][u][4 * q + 2] * inv);
+              v.w = __builtin_fmaf(d, b.w, acc[t][u][4 * q + 3] * inv);
+              v.x = __uint_as_float(__float_as_uint(v.x) & (unsigned)__builtin_amdgcn_sbfe(mw, 4 * q, 1));
+              v.y = __uint_as_float(__float_as_uint(v.y) & (unsigned)__builtin_amdgcn_sbfe(mw, 4 * q + 1, 1));
+              v.z = __uint_as_float(__float_as_uint(v.z) & (unsigned)__builtin_amdgcn_sbfe(mw, 4 * q + 2, 1));
+              v.w = __uint_as_float(__float_as_uint(v.w) & (unsigned)__builtin_amdgcn_sbfe(mw, 4 * q + 3, 1));
+              vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            } else {
+              // (the product with the power of two is exact, so the fused multiply-add rounds exactly as multiply, add would)
+              v.x = fmaxf(__builtin_fmaf(acc[t][u][4 * q], inv, b.x), 0.f);
+              v.y = fmaxf(__builtin_fmaf(acc[t][u][4 * q + 1], inv, b.y), 0.f);
+              v.z = fmaxf(__builtin_fmaf(acc[t][u][4 * q + 2], inv, b.z), 0.f);
+              v.w = fmaxf(__builtin_fmaf(acc[t][u][4 * q + 3], inv, b.w), 0.f);
+              vmax = fmaxf(vmax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            }
+            acc[t][u][4 * q] = v.x; acc[t][u][4 * q + 1] = v.y; acc[t][u][4 * q + 2] = v.z; acc[t][u][4 * q + 3] = v.w;
+            const int row = r0 + t * 32 + l31;
+            if (l == 7 && row < R && (!(TR_DBG & 2) || v.x == 123.456f)) *reinterpret_cast<float4*>(out + (size_t)row * ld + 32 * cb + 8 * q + 4 * lh) = v;   // (stages 0 .. 6 leave through the image)
           }
-          acc[t][4 * q] = v.x; acc[t][4 * q + 1] = v.y; acc[t][4 * q + 2] = v.z; acc[t][4 * q + 3] = v.w;
-          const int row = r0 + t * 32 + l31;
-          if (l == 7 && row < R && (!(TR_DBG & 2) || v.x == 123.456f)) *reinterpret_cast<float4*>(out + (size_t)row * ld + 32 * w + 8 * q + 4 * lh) = v;   // (stages 0 .. 6 leave through the image)
         }
       }
       if (!BWD && !(TR_DBG & 4)) {
         if (MROW) {
           uint16_t* __restrict__ br = T.bitsr[l];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            // bit j <-> accumulator register j of the lane.  The values are ReLU outputs (+0 or positive): bits + 0x7FFFFFFF
-            // carries into bit 31 exactly for the positive ones, and v_alignbit shifts that bit into the word - 2 instructions per value
-            unsigned m = 0u;
+          for (int t = 0; t < TM; ++t)
 #pragma unroll
-            for (int j = 15; j >= 0; --j) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[t][j]) + 0x7FFFFFFFu, 31);
-            const int row = r0 + t * 32 + l31;
-            if (row < R) br[((size_t)row * 8 + w) * 2 + lh] = (uint16_t)m;
-          }
+            for (int u = 0; u < TU; ++u) {
+              // bit j <-> accumulator register j of the lane.  The values are ReLU outputs (+0 or positive): bits + 0x7FFFFFFF
+              // carries into bit 31 exactly for the positive ones, and v_alignbit shifts that bit into the word - 2 instructions per value
+              unsigned m = 0u;
+#pragma unroll
+              for (int j = 15; j >= 0; --j) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[t][u][j]) + 0x7FFFFFFFu, 31);
+              const int row = r0 + t * 32 + l31;
+              if (row < R) br[((size_t)row * 8 + TU * w + u) * 2 + lh] = (uint16_t)m;
+            }
         } else {
           uint32_t* __restrict__ bits = T.bits[l];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            // lane c of rm <- the 32 row bits of column c: the 64-lane compare mask of accumulator register j is rows 0..31 of
-            // column (j & 3) + 8 (j >> 2) in its low word and of that column + 4 in its high word
-            unsigned rm = 0u;
+          for (int t = 0; t < TM; ++t)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-              const unsigned long long bal = __ballot(acc[t][j] > 0.f);
-              const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
-              TR_WRITELANE(rm, blo, (j & 3) + 8 * (j >> 2));
-              TR_WRITELANE(rm, bhi, (j & 3) + 8 * (j >> 2) + 4);
+            for (int u = 0; u < TU; ++u) {
+              // lane c of rm <- the 32 row bits of column c: the 64-lane compare mask of accumulator register j is rows 0..31 of
+              // column (j & 3) + 8 (j >> 2) in its low word and of that column + 4 in its high word
+              unsigned rm = 0u;
+#pragma unroll
+              for (int j = 0; j < 16; ++j) {
+                const unsigned long long bal = __ballot(acc[t][u][j] > 0.f);
+                const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
+                TR_WRITELANE(rm, blo, (j & 3) + 8 * (j >> 2));
+                TR_WRITELANE(rm, bhi, (j & 3) + 8 * (j >> 2) + 4);
+              }
+              // word of row half h' of a column = nibbles h', h' + 2, h' + 4, h' + 6 of its row bits; all 32 columns at once
+              unsigned e = rm & 0x0F0F0F0Fu, o = (rm >> 4) & 0x0F0F0F0Fu;
+              e = (e | (e >> 4)) & 0x00FF00FFu;
+              o = (o | (o >> 4)) & 0x00FF00FFu;
+              e = (e | (e >> 8)) & 0x0000FFFFu;
+              o = (o | (o >> 8)) & 0x0000FFFFu;
+              if (lane < 32) bits[((size_t)(r0 >> 5) + t) * 256 + 32 * (TU * w + u) + lane] = e | (o << 16);
             }
-            // word of row half h' of a column = nibbles h', h' + 2, h' + 4, h' + 6 of its row bits; all 32 columns at once
-            unsigned e = rm & 0x0F0F0F0Fu, o = (rm >> 4) & 0x0F0F0F0Fu;
-            e = (e | (e >> 4)) & 0x00FF00FFu;
-            o = (o | (o >> 4)) & 0x00FF00FFu;
-            e = (e | (e >> 8)) & 0x0000FFFFu;
-            o = (o | (o >> 8)) & 0x0000FFFFu;
-            if (lane < 32) bits[((size_t)(r0 >> 5) + t) * 256 + 32 * w + lane] = e | (o << 16);
-          }
         }
       }
       // maximum of each row of 16 lanes by four DPP moves (no LDS round trips, unlike __shfl_xor), then four lanes per
@@ -393,18 +430,24 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
       if (tid == 0) tmax[(l + 7) & 7] = 0.f;            // the slot of the stage before: read long ago, next written a tile from now
       const bool dens = !BWD && l == 6 && T.wd;
       if (dens) {
-        float p[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 c = *reinterpret_cast<const float4*>(wdl + 8 * q);
+        for (int u = 0; u < TU; ++u) {
+          const float* const wdl = wdl_ + 32 * (TU * w + u) + 4 * lh;
+          float p[TM];
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            p[t] += acc[t][4 * q] * c.x + acc[t][4 * q + 1] * c.y + acc[t][4 * q + 2] * c.z + acc[t][4 * q + 3] * c.w;
-        }
+          for (int t = 0; t < TM; ++t) p[t] = 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          p[t] += __shfl_xor(p[t], 32, 64);
-          if (lh == 0) dpart[w * 128 + t * 32 + l31] = p[t];
+          for (int q = 0; q < 4; ++q) {
+            const float4 c = *reinterpret_cast<const float4*>(wdl + 8 * q);
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+              p[t] += acc[t][u][4 * q] * c.x + acc[t][u][4 * q + 1] * c.y + acc[t][u][4 * q + 2] * c.z + acc[t][u][4 * q + 3] * c.w;
+          }
+#pragma unroll
+          for (int t = 0; t < TM; ++t) {
+            p[t] += __shfl_xor(p[t], 32, 64);
+            if (lh == 0) dpart[(TU * w + u) * TR + t * 32 + l31] = p[t];
+          }
         }
       }
       TR_TICK(2);
@@ -412,25 +455,29 @@ __global__ __launch_bounds__(512, 1) void k_nerf_trunk(TrunkArgs T, const int32_
       TR_TICK(3);
       const float tm = tmax[l];
       if (tid == 0) lmax[l] = fmaxf(lmax[l], tm);
-      if (dens && tid < 128) {
-        float s = bl[9 * 256];
+      if (!BWD && tid < 256) bl[((l + 1) & 1) * 256 + tid] = bnext;
+      if (dens && tid < TR) {
+        float s = wdl_[256];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += dpart[u * 128 + tid];
+        for (int u = 0; u < 8; ++u) s += dpart[u * TR + tid];
         if (r0 + tid < R) { T.raw[r0 + tid] = s; T.density[r0 + tid] = s > 20.f ? s : log1pf(expf(s)); }
       }
       if (l < 7) {
         sA = pp_split_scale((!BWD && l == 3) ? fmaxf(tm, in_max) : tm);     // layer 4 reads the encoded points at the same scale
-        unsigned char* const chunk = Img + w * PL_A_BYTES;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int u = 0; u < TU; ++u) {
+          unsigned char* const chunk = Img + (TU * w + u) * CH;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            pp_half4 h, lo;
-            pp_split4(make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]), sA, h, lo);
-            const int row = t * 32 + l31;
-            *reinterpret_cast<pp_half4*>(chunk + pl_slot_off(row, q) + 8 * lh) = h;
-            *reinterpret_cast<pp_half4*>(chunk + pl_slot_off(row, 4 + q) + 8 * lh) = lo;
-          }
+          for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              pp_half4 h, lo;
+              pp_split4(make_float4(acc[t][u][4 * q], acc[t][u][4 * q + 1], acc[t][u][4 * q + 2], acc[t][u][4 * q + 3]), sA, h, lo);
+              const int row = t * 32 + l31;
+              *reinterpret_cast<pp_half4*>(chunk + pl_slot_off(row, q) + 8 * lh) = h;
+              *reinterpret_cast<pp_half4*>(chunk + pl_slot_off(row, 4 + q) + 8 * lh) = lo;
+            }
+        }
       }
       TR_TICK(4);
       TR_BARRIER();                                     // B: the next stage's image is complete
