@@ -441,8 +441,11 @@ def dual_branch_leg(eng, idx_all, jit_all, gs, N, V, H, W, object_ms, dev, steps
             issued = (3 if split else 1) * 3 * fl_sample * samples           # matrix-pipe FLOPs actually issued
             peak = FP16_MFMA_PEAK_TF if split else FP32_MFMA_PEAK_TF
             out['roofline_scene'] = {
-                'bound': 'mfma', 'kernel': 'pp_nerf_fwd + pp_nerf_bwd: 9 forward, 10 data-gradient and 9 weight-gradient GEMMs of the '
-                                           '8x256 NeRF (+ encoding / head kernels, ~10 % of the time)',
+                'bound': 'mfma', 'kernel': ('pp_nerf_fwd + pp_nerf_bwd: the eight feature layers + density head as ONE kernel (tile resident in LDS), '
+                                           'their data-gradient chain as one more, colour-head GEMMs, 9 weight-gradient GEMMs of the 8x256 NeRF '
+                                           '(+ encoding / head kernels)') if _lib.get_option('nerf_chain') == 3 else
+                                          ('pp_nerf_fwd + pp_nerf_bwd: 9 forward, 10 data-gradient and 9 weight-gradient GEMMs of the '
+                                           '8x256 NeRF (+ encoding / head kernels, ~10 % of the time)'),
                 'achieved': issued / (chain_ms * 1e-3) / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
                 'frac': issued / (chain_ms * 1e-3) / 1e12 / peak, 'traffic': None, 'ms_per_step': chain_ms,
                 'pipe': 'fp16 MFMA (3 products per fp32 product)' if split else 'fp32 MFMA',

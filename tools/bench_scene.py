@@ -9,7 +9,8 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 opt = bg_nerf.default_options()
 chain = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 nw = int(sys.argv[5]) if len(sys.argv) > 5 else 4
-net = bg_nerf.NeRF(opt, device='cuda', options={'nerf_chain': chain, 'nerf_chain_nw': nw}); net.progress.data.fill_(0.6)
+extra = {k: int(v) for k, v in (a.split('=') for a in sys.argv[6:])}
+net = bg_nerf.NeRF(opt, device='cuda', options={'nerf_chain': chain, 'nerf_chain_nw': nw, **extra}); net.progress.data.fill_(0.6)
 eng = bg_nerf.SceneEngine(net, lr=1e-3)
 g = torch.Generator().manual_seed(0)
 center = (torch.randn(R, 3, generator=g) * 0.3).cuda()
@@ -26,4 +27,4 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 M = R * S
 fl_fwd = 2 * M * (64 * 256 + 256 * 256 * 6 + 320 * 256 + 256 + 288 * 128 + 128 * 3)
-print(json.dumps(dict(nerf_chain=chain, nw=nw, rays=R, samples=S, ms_per_step=dt * 1e3, rays_per_s=R / dt, tflops=3 * fl_fwd / dt / 1e12, loss=float(loss))))
+print(json.dumps(dict(nerf_chain=chain, nw=nw, **extra, rays=R, samples=S, ms_per_step=dt * 1e3, rays_per_s=R / dt, tflops=3 * fl_fwd / dt / 1e12, loss=float(loss))))
