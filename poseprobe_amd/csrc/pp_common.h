@@ -37,6 +37,7 @@ enum PPOption {
   PP_OPT_NERF_CHAIN,           // scene branch: bit 1 = the eight feature layers + density head of the forward pass as one kernel with the tile resident in LDS
                                // (pp_nerf_trunk.h), 3 = the data-gradient chain of the backward pass too (0 = one GEMM per layer)
   PP_OPT_NERF_CHAIN_NW,        // scene branch: wavefronts per work-group of the fused chains (8: one 128-sample tile per CU, 4: two 64-sample tiles per CU)
+  PP_OPT_NERF_CHAIN_HEAD,      // scene branch: 1 = the colour head's hidden layer as a ninth stage of the fused forward chain
   PP_OPT_COUNT
 };
 

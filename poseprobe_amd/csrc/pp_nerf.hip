@@ -79,7 +79,7 @@ static NerfActs nerf_acts(float* base, int64_t M) {
   for (int l = 0; l < 8; ++l) { A.wimg[l] = reinterpret_cast<_Float16*>(p); p += 256 * NERF_IN_LD[l]; }   // hi + lo halfs = 4 B per weight
   return A;
 }
-static const int64_t NERF_WIMG_FLOATS = 256 * (64 + 256 * 6 + 320);
+static const int64_t NERF_WIMG_FLOATS = 256 * (64 + 256 * 6 + 320) + 10 * 8192;   // + the head stage's ten steps of the fused chain's weight stream (pp_nerf_trunk.h)
 static int64_t nerf_acts_floats(int64_t M) {
   return M * (64 + 256 * 6 + 320 + 288 + 128 + 1) + MX_SLOTS + (M + 127) / 128 * 128 * 64 + NERF_WIMG_FLOATS;
 }
@@ -681,6 +681,8 @@ static int nerf_wide_tiles() { return pp_opt(PP_OPT_NERF_BN) == 256; }
 //   nerf_chain_nw      wavefronts per work-group of the fused chains: 8 = one work-group on a 128-sample tile per CU, 4 = two work-groups on
 //                      64-sample tiles per CU (one's epilogue beside the other's matrix instructions; twice the weight traffic from L2)
 #define NERF_CHAIN_NW pp_opt(PP_OPT_NERF_CHAIN_NW)
+//   nerf_chain_head    1: the colour head's 288 -> 128 layer rides as a ninth stage of the fused forward chain
+#define NERF_CHAIN_HEAD (pp_opt(PP_OPT_NERF_CHAIN_HEAD) == 1)
 
 template <int EPI>
 static void nerf_gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, int K, int Nout, const float* bias,
@@ -778,7 +780,9 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
     if (NERF_CHAIN) {
       TrunkPackJobs P;
       for (int l = 0; l < 8; ++l) { P.src[l] = params + L.w[l]; P.ld[l] = NERF_IN_LD[l]; P.mx_w[l] = MX_W0 + l; }
-      hipLaunchKernelGGL(k_pack_trunk<false>, dim3(TR_STEPS * 4), dim3(256), 0, st, P, mx, reinterpret_cast<unsigned char*>(A.wimg[0]));
+      P.src[8] = params + L.r0; P.ld[8] = 288; P.mx_w[8] = MX_R0;        // the colour head's hidden layer rides as a ninth stage
+      P.nsteps = NERF_CHAIN_HEAD ? TR_STEPS + 10 : TR_STEPS; P.nw = NERF_CHAIN_NW == 4 ? 4 : 8;
+      hipLaunchKernelGGL(k_pack_trunk<false>, dim3(P.nsteps * 4), dim3(256), 0, st, P, mx, reinterpret_cast<unsigned char*>(A.wimg[0]));
     } else if (NERF_PLANES) {
       PlanePackJobs P;
       P.n = 8;
@@ -801,6 +805,7 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
     T.wstream = reinterpret_cast<const unsigned char*>(A.wimg[0]);
     T.wd = params + L.wd; T.bd = params + L.bd; T.raw = A.raw; T.density = density_samples;
     T.mx = mx; T.mx_in = MX_ENC;
+    T.head = NERF_CHAIN_HEAD; T.out[8] = A.h; T.ld[8] = 128; T.bias[8] = params + L.br0; T.mx_w[8] = MX_R0; T.in2 = A.a[7] + 256; T.in2_ld = 288;
     const int cus = pp_num_cus();
     if (NERF_CHAIN_NW == 4) {                       // 64-row tiles, two work-groups per CU
       const int tiles = pp_div_up(M, 64), grid = tiles < 2 * cus ? tiles : 2 * cus;
@@ -822,8 +827,9 @@ extern "C" int pp_nerf_fwd(const float* params, const float* center, const float
     hipLaunchKernelGGL(k_nerf_density_fwd, dim3(pp_div_up(M, 4)), dim3(256), 0, st, A.a[6], params + L.wd, params + L.bd, M,
                        A.raw, density_samples);
   }
-  nerf_gemm<EPI_RELU>(st, A.a[7], 288, params + L.r0, 288, 288, 128, params + L.br0, nullptr, 0, A.h, 128, count, M,
-                      mx ? mx + MX_A0 + 7 : nullptr, mx ? mx + MX_R0 : nullptr, nullptr);
+  if (!(mx && NERF_CHAIN && NERF_CHAIN_HEAD))         // (else the fused chain has produced the head's hidden layer as its ninth stage)
+    nerf_gemm<EPI_RELU>(st, A.a[7], 288, params + L.r0, 288, 288, 128, params + L.br0, nullptr, 0, A.h, 128, count, M,
+                        mx ? mx + MX_A0 + 7 : nullptr, mx ? mx + MX_R0 : nullptr, nullptr);
   hipLaunchKernelGGL(k_nerf_rgb_fwd, dim3(pp_div_up(M * 16, 256)), dim3(256), 0, st, params + L.r1, params + L.br1, A.h, M,
                      rgb_samples);
   PP_CHECK_LAUNCH();
@@ -885,6 +891,7 @@ extern "C" int pp_nerf_bwd(const float* params, const float* ray, const float* d
     TrunkPackJobs J;
     J.src[0] = params + L.r0; J.ld[0] = 288; J.mx_w[0] = MX_R0;
     for (int s_ = 1; s_ < 8; ++s_) { J.src[s_] = params + L.w[8 - s_]; J.ld[s_] = NERF_IN_LD[8 - s_]; J.mx_w[s_] = MX_W0 + 8 - s_; }
+    J.nsteps = TR_STEPS; J.nw = 0;
     hipLaunchKernelGGL(k_pack_trunk<true>, dim3(TR_STEPS * 4), dim3(256), 0, st, J, mx, reinterpret_cast<unsigned char*>(r0t_img));
   } else if (planes) {
     PlanePackJobs P;

@@ -59,9 +59,9 @@ extern "C" int pp_debug_read_trunk_timers(unsigned long long* out16, int reset) 
 struct TrunkArgs {
   const float* in;                      // what the chain reads from HBM: forward [M][64] encoded points, backward [M][128] d(hidden of the colour head)
   int in_ld;
-  float* out[8];                        // stage outputs, fp32 [M][ld]
-  int ld[8];
-  const float* bias[8];                 // forward
+  float* out[9];                        // stage outputs, fp32 [M][ld] (forward stage 8 = the colour head's hidden layer, [M][128])
+  int ld[9];
+  const float* bias[9];                 // forward
   uint32_t* bits[8];                    // forward, MROW = false: ReLU masks in the layer-by-layer layout (pairs of its 16-bit words)
   uint16_t* bitsr[8];                   // MROW: [row][8 wavefronts][2 lane halves] words; forward writes stage s's, backward reads the mask of stage s's OUTPUT
   const unsigned char* wstream;         // k_pack_trunk's image
@@ -73,7 +73,10 @@ struct TrunkArgs {
   int draw_ld;
   float* mx;                            // operand-maximum slots
   int mx_in;                            // slot of `in`
-  int mx_w[8], mx_out[8];               // per stage: slot of the weights, slot recording the output
+  int mx_w[9], mx_out[8];               // per stage: slot of the weights, slot recording the output
+  int head;                             // forward: 1 = stage 8, the colour head's 288 -> 128 layer on layer 7's tile + the view columns (read at in2)
+  const float* in2;                     // forward with head: [M][in2_ld] view-direction encoding, 32 columns
+  int in2_ld;
 };
 
 __host__ __device__ __forceinline__ void tr_step_layer(int g, int& l, int& kc) {      // forward: step -> layer, K-chunk
@@ -88,19 +91,31 @@ __host__ __device__ __forceinline__ void tr_step_layer(int g, int& l, int& kc) {
 // backward  stage s = 0: R0[i][o], stages 1 .. 7: W_{8 - s}[i][o] with o = 32 w + (lane & 31), i = 32 kc + 16 ks + 8 (lane >> 5) .. + 7
 //           (src[s] = the stage's matrix with rows i, [.][ld]: the transposed read happens here, once per pass)
 // scaled by the matrix' power of two (slot mx_w[stage])
-struct TrunkPackJobs { const float* src[8]; int ld[8]; int mx_w[8]; };
+struct TrunkPackJobs { const float* src[9]; int ld[9]; int mx_w[9]; int nsteps; int nw; };
 template <bool BWD>
 static __global__ __launch_bounds__(256) void k_pack_trunk(TrunkPackJobs J, const float* __restrict__ mx, unsigned char* __restrict__ dst) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= TR_STEPS * 1024) return;
+  if (e >= J.nsteps * 1024) return;
   const int lane = e & 63, ks = (e >> 6) & 1, w = (e >> 7) & 7, g = e >> 10;
   int l, kc;
   if (BWD) { l = g < 4 ? 0 : 1 + ((g - 4) >> 3); kc = g < 4 ? g : (g - 4) & 7; }
-  else tr_step_layer(g, l, kc);
+  else if (g < TR_STEPS) tr_step_layer(g, l, kc);
+  else { l = 8; kc = g == TR_STEPS ? 8 : g - TR_STEPS - 2; }          // head: the view chunk (input columns 256 .. 287), a zero step, chunks 0 .. 7
   const float s = pp_split_scale(mx[J.mx_w[l]]);
-  const int o = 32 * w + (lane & 31), i0 = kc * 32 + ks * 16 + (lane >> 5) * 8;
+  // column block this slot of the stream feeds: the wavefront's own everywhere except in the head stage, whose 128 columns are
+  // blocks 0 .. 3: with four wavefronts (two slots each) wavefront w takes block w in its FIRST slot, with eight wavefront w < 4 block w
+  int blk = w;
+  bool zero = false;
+  if (!BWD && l == 8) {
+    if (J.nw == 4) { blk = w >> 1; zero = (w & 1) != 0; } else zero = w >= 4;
+    if (g == TR_STEPS + 1) zero = true;
+  }
+  const int o = 32 * blk + (lane & 31), i0 = kc * 32 + ks * 16 + (lane >> 5) * 8;
   float v[8];
-  if (BWD) {
+  if (zero) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = 0.f;
+  } else if (BWD) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = J.src[l][(size_t)(i0 + u) * J.ld[l] + o];
   } else {
@@ -117,7 +132,7 @@ static __global__ __launch_bounds__(256) void k_pack_trunk(TrunkPackJobs J, cons
 
 // one K-chunk: TM x TU x 6 matrix instructions per wavefront on the chunk image `img` (TM blocks of 32 rows, `rb` bytes apart)
 // and the weight registers wb = TU column blocks x 2 halves x {hi, lo}
-template <int TM, int TU>
+template <int TM, int TU, int NU = TU>
 __device__ __forceinline__ void tr_step(const unsigned char* img, const pp_half8 (&wb)[TU * 4], f32x16 (&acc)[TM][TU], int l31, int lh) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
@@ -136,15 +151,15 @@ __device__ __forceinline__ void tr_step(const unsigned char* img, const pp_half8
     }
     // small terms first; the three products of one block are TM x TU instructions apart
 #pragma unroll
-    for (int u = 0; u < TU; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int t = 0; t < TM; ++t) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[u * 4 + ks * 2 + 1], ah[t], acc[t][u], 0, 0, 0);
 #pragma unroll
-    for (int u = 0; u < TU; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int t = 0; t < TM; ++t) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[u * 4 + ks * 2], al[t], acc[t][u], 0, 0, 0);
 #pragma unroll
-    for (int u = 0; u < TU; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int t = 0; t < TM; ++t) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[u * 4 + ks * 2], ah[t], acc[t][u], 0, 0, 0);
   }
@@ -191,7 +206,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_nerf_trunk(TrunkAr
   const int l31 = lane & 31, lh = lane >> 5;
   const float in_max = T.mx[T.mx_in];
   const float sE = pp_split_scale(in_max);
-  if (tid < 8) { tmax[tid] = 0.f; lmax[tid] = 0.f; swl[tid] = pp_split_scale(T.mx[T.mx_w[tid]]); }
+  const bool head = !BWD && T.head;                     // forward: a ninth stage, the colour head's hidden layer
+  const int NS = head ? 9 : 8, nsteps = head ? TR_STEPS + 10 : TR_STEPS;
+  if (tid < 8) { tmax[tid] = 0.f; lmax[tid] = 0.f; }
+  if (tid < NS) swl[tid] = pp_split_scale(T.mx[T.mx_w[tid]]);
   if (tid == 0) wdl_[256] = (!BWD && T.bd) ? T.bd[0] : 0.f;
   for (int i = tid; i < 256; i += NT) { wdl_[i] = T.wd ? T.wd[i] : 0.f; bl[i] = BWD ? 0.f : T.bias[0][i]; }
 
@@ -204,7 +222,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_nerf_trunk(TrunkAr
     const unsigned char* p_ = wbase + (size_t)gs * TR_WSTEP;                                              \
     if (!(TR_DBG & 8) || first_)                                                                          \
     _Pragma("unroll") for (int i_ = 0; i_ < TU * 4; ++i_) (wb)[i_] = *reinterpret_cast<const pp_half8*>(p_ + i_ * 1024); \
-    gs = gs + 1 == TR_STEPS ? 0 : gs + 1;                                                                 \
+    gs = gs + 1 == nsteps ? 0 : gs + 1;                                                                   \
   } while (0)
   bool first_ = true;
   TR_WLOAD(wb0);
@@ -230,8 +248,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_nerf_trunk(TrunkAr
     *reinterpret_cast<pp_half8*>(E + pl_slot_off(tid >> 2, tid & 3)) = h_;                                \
     *reinterpret_cast<pp_half8*>(E + pl_slot_off(tid >> 2, 4 + (tid & 3))) = l_;                          \
   } while (0)
+  // head stage: the tile's 32 view-encoding columns, fetched a stage ahead
+  float4 pv[2];
+#define TR_VLOAD(tile_)                                                                                   \
+  do {                                                                                                    \
+    const int row_ = min((tile_) * TR + (tid >> 2), R - 1);                                               \
+    const float* p_ = T.in2 + (size_t)row_ * T.in2_ld + (tid & 3) * 8;                                    \
+    pv[0] = *reinterpret_cast<const float4*>(p_);                                                         \
+    pv[1] = *reinterpret_cast<const float4*>(p_ + 4);                                                     \
+  } while (0)
   TR_ELOAD((int)blockIdx.x);
   TR_BARRIER();
+  int bp = 0;                                           // which half of bl holds the current stage's bias
 #ifdef TR_TIMERS
   unsigned long long tsum[8] = {0}, tprev = __builtin_readcyclecounter();
 #endif
@@ -239,7 +267,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_nerf_trunk(TrunkAr
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int r0 = tile * TR;
     float sA = sE;                                      // scale of the current stage's input
-    for (int l = 0; l < 8; ++l) {
+    for (int l = 0; l < NS; ++l) {
       f32x16 acc[TM][TU];
 #pragma unroll
       for (int t = 0; t < TM; ++t)
@@ -249,8 +277,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_nerf_trunk(TrunkAr
           for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
       // forward: the next stage's bias on its way to LDS (fetched here, written behind barrier A, read a stage later)
       float bnext = 0.f;
-      if (!BWD && tid < 256) bnext = T.bias[(l + 1) & 7][tid];
+      if (!BWD && tid < (l == 7 && head ? 128 : 256)) bnext = T.bias[l + 1 == NS ? 0 : l + 1][tid];
       TR_TICK(6);
+      if (!BWD && l == 8) {                             // head: the view columns through E, then a zero-weight step (keeps the two weight register sets in step)
+        const float v_[8] = {pv[0].x, pv[0].y, pv[0].z, pv[0].w, pv[1].x, pv[1].y, pv[1].z, pv[1].w};
+        pp_half8 h_, l_;
+        pp_split8(v_, sA, h_, l_);
+        *reinterpret_cast<pp_half8*>(E + pl_slot_off(tid >> 2, tid & 3)) = h_;
+        *reinterpret_cast<pp_half8*>(E + pl_slot_off(tid >> 2, 4 + (tid & 3))) = l_;
+        TR_BARRIER();
+        tr_step<TM, TU>(E, wb0, acc, l31, lh);
+        TR_WLOAD(wb0);
+        tr_step<TM, TU>(E, wb1, acc, l31, lh);
+        TR_WLOAD(wb1);
+        TR_BARRIER();
+      }
       if (l == 0 || (!BWD && l == 4)) {                 // the streamed columns, one chunk at a time through E
         TR_ECONV(0, sA);
         if (BWD) TR_ELOAD1(0, tile, 2);
@@ -280,6 +321,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_nerf_trunk(TrunkAr
       TR_TICK(0);
       if (!BWD && l == 3) TR_ELOAD(tile);               // for layer 4 of this tile
       if (l == 7) TR_ELOAD(tile + (int)gridDim.x);      // for stage 0 of the next one (rows are clamped)
+      if (!BWD && head && l == 6) TR_VLOAD(tile);       // for the head stage of this one
       // backward: the epilogue's per-row operands, fetched before the resident chunks so that their latency is long over
       // (d raw of the tile's rows waits in LDS - dpart is otherwise unused in the backward chain - from stage 0 to the epilogue of stage 1)
       unsigned mword[TM][TU];
@@ -307,30 +349,38 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_nerf_trunk(TrunkAr
         const int drow = 16 * w + (lane >> 2), dc8 = lane & 3;
         const bool dok = r0 + drow < R;
         float* const dptr = outp + (size_t)(r0 + drow) * ldp + 8 * dc8;
+#define TR_DRAIN(kc)                                                                                      \
+        do {                                                                                              \
+            if (!(TR_DBG & 2)) {                                                                        \
+              const pp_half8 h = *reinterpret_cast<const pp_half8*>(Img + kc * CH + pl_slot_off(drow, dc8));\
+              const pp_half8 lo = *reinterpret_cast<const pp_half8*>(Img + kc * CH + pl_slot_off(drow, 4 + dc8));\
+              typedef float tr_f4 __attribute__((ext_vector_type(4)));                                  \
+              tr_f4 a, b;                                                                               \
+              a.x = ((float)h[0] + (float)lo[0]) * invs; a.y = ((float)h[1] + (float)lo[1]) * invs;     \
+              a.z = ((float)h[2] + (float)lo[2]) * invs; a.w = ((float)h[3] + (float)lo[3]) * invs;     \
+              b.x = ((float)h[4] + (float)lo[4]) * invs; b.y = ((float)h[5] + (float)lo[5]) * invs;     \
+              b.z = ((float)h[6] + (float)lo[6]) * invs; b.w = ((float)h[7] + (float)lo[7]) * invs;     \
+              if (dok) {                                                                                \
+                if (TR_NT) {                                                                            \
+                  __builtin_nontemporal_store(a, reinterpret_cast<tr_f4*>(dptr + 32 * kc));             \
+                  __builtin_nontemporal_store(b, reinterpret_cast<tr_f4*>(dptr + 32 * kc + 4));         \
+                } else {                                                                                \
+                  *reinterpret_cast<tr_f4*>(dptr + 32 * kc) = a;                                        \
+                  *reinterpret_cast<tr_f4*>(dptr + 32 * kc + 4) = b;                                    \
+                }                                                                                       \
+              }                                                                                         \
+            }                                                                                           \
+        } while (0)
+        // (the head stage runs like every other one - its 128 columns sit in the wavefronts' first slots, the other slots multiply
+        // zero weights: a narrower variant of the step for that stage alone, as a second unrolled loop or as a test inside this
+        // one, cost 260-350 bytes of register spills per lane)
 #pragma unroll
         for (int kc = 0; kc < 8; ++kc) {
           if (kc & 1) { tr_step<TM, TU>(Img + kc * CH, wb1, acc, l31, lh); TR_WLOAD(wb1); }
           else { tr_step<TM, TU>(Img + kc * CH, wb0, acc, l31, lh); TR_WLOAD(wb0); }
-          if (!(TR_DBG & 2)) {
-            const pp_half8 h = *reinterpret_cast<const pp_half8*>(Img + kc * CH + pl_slot_off(drow, dc8));
-            const pp_half8 lo = *reinterpret_cast<const pp_half8*>(Img + kc * CH + pl_slot_off(drow, 4 + dc8));
-            typedef float tr_f4 __attribute__((ext_vector_type(4)));
-            tr_f4 a, b;
-            a.x = ((float)h[0] + (float)lo[0]) * invs; a.y = ((float)h[1] + (float)lo[1]) * invs;
-            a.z = ((float)h[2] + (float)lo[2]) * invs; a.w = ((float)h[3] + (float)lo[3]) * invs;
-            b.x = ((float)h[4] + (float)lo[4]) * invs; b.y = ((float)h[5] + (float)lo[5]) * invs;
-            b.z = ((float)h[6] + (float)lo[6]) * invs; b.w = ((float)h[7] + (float)lo[7]) * invs;
-            if (dok) {
-              if (TR_NT) {
-                __builtin_nontemporal_store(a, reinterpret_cast<tr_f4*>(dptr + 32 * kc));
-                __builtin_nontemporal_store(b, reinterpret_cast<tr_f4*>(dptr + 32 * kc + 4));
-              } else {
-                *reinterpret_cast<tr_f4*>(dptr + 32 * kc) = a;
-                *reinterpret_cast<tr_f4*>(dptr + 32 * kc + 4) = b;
-              }
-            }
-          }
+          TR_DRAIN(kc);
         }
+#undef TR_DRAIN
       }
       TR_TICK(1);
       // ---- epilogue.  forward: bias, ReLU, masks; backward: mask (+ the density term); then the tile maximum
@@ -338,10 +388,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_nerf_trunk(TrunkAr
       float* __restrict__ out = T.out[l];
       const int ld = T.ld[l];
       float vmax = 0.f;
+      const bool hstage = !BWD && l == 8;               // head stage: block w of four, first slot only
+      const bool last = l == NS - 1;
 #pragma unroll
       for (int u = 0; u < TU; ++u) {
-        const int cb = TU * w + u;                      // 32-column block of the stage's output = K-chunk of the next stage
-        const float* const bias = bl + (l & 1) * 256 + 32 * cb + 4 * lh;
+        // (head stage: the slots without a block still run the arithmetic on zeros - skipping it would make the 64 accumulators
+        // conditionally updated values, which the register allocator pays for with spills - and store nothing)
+        const bool live = !hstage || (u == 0 && (NW == 4 || w < 4));
+        const int cb = hstage ? (w & 3) : TU * w + u;   // 32-column block of the stage's output = K-chunk of the next stage
+        const float* const bias = bl + bp * 256 + 32 * cb + 4 * lh;
         const float* const wdl = wdl_ + 32 * cb + 4 * lh;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -372,11 +427,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_nerf_trunk(TrunkAr
             }
             acc[t][u][4 * q] = v.x; acc[t][u][4 * q + 1] = v.y; acc[t][u][4 * q + 2] = v.z; acc[t][u][4 * q + 3] = v.w;
             const int row = r0 + t * 32 + l31;
-            if (l == 7 && row < R && (!(TR_DBG & 2) || v.x == 123.456f)) *reinterpret_cast<float4*>(out + (size_t)row * ld + 32 * cb + 8 * q + 4 * lh) = v;   // (stages 0 .. 6 leave through the image)
+            if (last && live && row < R && (!(TR_DBG & 2) || v.x == 123.456f)) *reinterpret_cast<float4*>(out + (size_t)row * ld + 32 * cb + 8 * q + 4 * lh) = v;   // (the other stages leave through the image)
           }
         }
       }
-      if (!BWD && !(TR_DBG & 4)) {
+      if (!BWD && !hstage && !(TR_DBG & 4)) {
         if (MROW) {
           uint16_t* __restrict__ br = T.bitsr[l];
 #pragma unroll
@@ -425,7 +480,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_nerf_trunk(TrunkAr
         vi = max(vi, __builtin_amdgcn_mov_dpp(vi, 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
         vi = max(vi, __builtin_amdgcn_mov_dpp(vi, 0x141, 0xF, 0xF, true));    // row_half_mirror
         vi = max(vi, __builtin_amdgcn_mov_dpp(vi, 0x140, 0xF, 0xF, true));    // row_mirror
-        if ((lane & 15) == 0) atomicMax(reinterpret_cast<unsigned int*>(tmax + l), (unsigned)vi);
+        if ((lane & 15) == 0 && !hstage) atomicMax(reinterpret_cast<unsigned int*>(tmax + l), (unsigned)vi);
       }
       if (tid == 0) tmax[(l + 7) & 7] = 0.f;            // the slot of the stage before: read long ago, next written a tile from now
       const bool dens = !BWD && l == 6 && T.wd;
@@ -453,17 +508,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_nerf_trunk(TrunkAr
       TR_TICK(2);
       TR_BARRIER();                                     // A: every wavefront is done with the image; maximum and partials complete
       TR_TICK(3);
-      const float tm = tmax[l];
-      if (tid == 0) lmax[l] = fmaxf(lmax[l], tm);
-      if (!BWD && tid < 256) bl[((l + 1) & 1) * 256 + tid] = bnext;
+      const float tm = hstage ? 0.f : tmax[l];
+      if (tid == 0 && !hstage) lmax[l] = fmaxf(lmax[l], tm);
+      if (!BWD && tid < 256) bl[(bp ^ 1) * 256 + tid] = bnext;
+      bp ^= 1;
       if (dens && tid < TR) {
         float s = wdl_[256];
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += dpart[u * TR + tid];
         if (r0 + tid < R) { T.raw[r0 + tid] = s; T.density[r0 + tid] = s > 20.f ? s : log1pf(expf(s)); }
       }
-      if (l < 7) {
-        sA = pp_split_scale((!BWD && l == 3) ? fmaxf(tm, in_max) : tm);     // layer 4 reads the encoded points at the same scale
+      if (!last) {
+        // layer 4 reads the encoded points, the head the view encoding (bounded by 1), at the same scale as the tile
+        sA = pp_split_scale((!BWD && l == 3) ? fmaxf(tm, in_max) : (!BWD && l == 7) ? fmaxf(tm, 1.f) : tm);
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
           unsigned char* const chunk = Img + (TU * w + u) * CH;
@@ -492,5 +549,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_nerf_trunk(TrunkAr
 #undef TR_WLOAD
 #undef TR_ELOAD
 #undef TR_ELOAD1
+#undef TR_VLOAD
 #undef TR_ECONV
 }

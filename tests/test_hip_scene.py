@@ -711,8 +711,9 @@ def test_scene_kernels_stay_inside_their_buffers(nerf_split):
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize('R,S,chain,nw', [(1023, 128, 3, 4), (1023, 128, 3, 8), (1023, 128, 1, 4), (37, 50, 3, 4), (37, 50, 1, 8), (1, 2, 3, 4)])
-def test_scene_trunk_kernel_equals_layer_by_layer_path(R, S, chain, nw):
+@pytest.mark.parametrize('R,S,chain,nw,head', [(1023, 128, 3, 4, 1), (1023, 128, 3, 8, 1), (1023, 128, 1, 4, 0), (37, 50, 3, 4, 0), (37, 50, 1, 8, 1),
+                                                (1, 2, 3, 4, 1)])
+def test_scene_trunk_kernel_equals_layer_by_layer_path(R, S, chain, nw, head):
     """Option nerf_chain (csrc/pp_nerf_trunk.h: the eight feature layers + density head as one kernel, tile resident in LDS)
     against the layer-by-layer GEMMs on the same inputs: every stored activation, the raw density and the sample outputs
     agree to fp32 rounding of a 256..320-term sum (the two paths scale their fp16 operand pairs by different powers of two -
@@ -722,12 +723,13 @@ def test_scene_trunk_kernel_equals_layer_by_layer_path(R, S, chain, nw):
     forward writing the masks in the layer-by-layer layout; chain = 3: in the fused chains' own layout ([row][wavefront][lane
     half], bit j <-> column 32 w + 4 half + (j & 3) + 8 (j >> 2)), followed by a backward pass of both paths on the same
     upstream gradients (parameter, centre and ray gradients).  nw: wavefronts per work-group of the fused kernels (8 on a
-    128-sample tile, one work-group per CU; 4 on a 64-sample tile, two per CU)."""
+    128-sample tile, one work-group per CU; 4 on a 64-sample tile, two per CU); head: the colour head's hidden layer as the
+    forward chain's ninth stage (compared through the sample colours)."""
     from poseprobe_amd import bg_nerf, ops
     dev = 'cuda'
     opt = bg_nerf.default_options(sample_intvs=S)
     torch.manual_seed(5)
-    nets = [bg_nerf.NeRF(opt, device=dev, options={'nerf_chain': c, 'nerf_chain_nw': nw}) for c in (chain, 0)]
+    nets = [bg_nerf.NeRF(opt, device=dev, options={'nerf_chain': c, 'nerf_chain_nw': nw, 'nerf_chain_head': head}) for c in (chain, 0)]
     g = torch.Generator().manual_seed(R + S)
     with torch.no_grad():
         for lin in list(nets[0].mlp_feat) + list(nets[0].mlp_rgb):
