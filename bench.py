@@ -442,7 +442,7 @@ def dual_branch_leg(eng, idx_all, jit_all, gs, N, V, H, W, object_ms, dev, steps
             peak = FP16_MFMA_PEAK_TF if split else FP32_MFMA_PEAK_TF
             out['roofline_scene'] = {
                 'bound': 'mfma', 'kernel': ('pp_nerf_fwd + pp_nerf_bwd: the eight feature layers + density head as ONE kernel (tile resident in LDS), '
-                                           'their data-gradient chain as one more, colour-head GEMMs, 9 weight-gradient GEMMs of the 8x256 NeRF '
+                                           'the colour head\'s hidden layer as its ninth stage, their data-gradient chain as one more, 9 weight-gradient GEMMs of the 8x256 NeRF '
                                            '(+ encoding / head kernels)') if _lib.get_option('nerf_chain') == 3 else
                                           ('pp_nerf_fwd + pp_nerf_bwd: 9 forward, 10 data-gradient and 9 weight-gradient GEMMs of the '
                                            '8x256 NeRF (+ encoding / head kernels, ~10 % of the time)'),
