@@ -224,7 +224,7 @@ int pp_color_feat_bwd(const pp_scene* sc, const float* k0_cl, const float* pts, 
  * coexist in one process and on concurrent threads (a context itself must not be modified while a call uses it).
  * Names (meaning and ranges: csrc/pp_common.h, csrc/pp_error.hip):
  *   arithmetic   mlp_split (bit mask: object-branch MLP kernels as 3 fp16 products per fp32 product; 0 = fp32 MFMA instructions),
- *                nerf_split, nerf_split_tn (scene branch likewise), mlp_fused, wgrad_split, nerf_bitmask, nerf_planes, nerf_chain, nerf_tn256
+ *                nerf_split, nerf_split_tn (scene branch likewise), mlp_fused, wgrad_split, nerf_bitmask, nerf_planes, nerf_chain, nerf_tn256, nerf_tn_tr
  *   scheduling   side_stream, mlp_wgs, wgrad_side_wgs, grid_chunks, nerf_gemm_wgs, nerf_tn_ch, nerf_tn_split_wgs, nerf_tn_wgs, nerf_bn, nerf_chain_nw, nerf_chain_head
  * pp_nerf_fwd and pp_nerf_bwd of one pass (and the two stages of a two-stage backward) must see the same option values.
  * Unknown names / out-of-range values are refused; pp_context_get_option(NULL, ...) reads the defaults. */

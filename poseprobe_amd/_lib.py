@@ -92,7 +92,7 @@ def header_abi_version(path=HEADER):
 # context (A/B scripts, tests); engines built with `options=...` own a private context and are unaffected by it.
 OPTION_NAMES = ('mlp_fused', 'wgrad_split', 'grid_chunks', 'nerf_split', 'nerf_split_tn', 'nerf_bitmask', 'nerf_gemm_wgs',
                 'nerf_tn_ch', 'nerf_tn_split_wgs', 'nerf_tn_wgs', 'nerf_bn', 'nerf_planes', 'mlp_split', 'nerf_tn256', 'mlp_wgs',
-                'wgrad_side_wgs', 'side_stream', 'nerf_chain', 'nerf_chain_nw', 'nerf_chain_head')
+                'wgrad_side_wgs', 'side_stream', 'nerf_chain', 'nerf_chain_nw', 'nerf_chain_head', 'nerf_tn_tr')
 
 
 class Context:

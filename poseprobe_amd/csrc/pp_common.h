@@ -38,6 +38,7 @@ enum PPOption {
                                // (pp_nerf_trunk.h), 3 = the data-gradient chain of the backward pass too (0 = one GEMM per layer)
   PP_OPT_NERF_CHAIN_NW,        // scene branch: wavefronts per work-group of the fused chains (8: one 128-sample tile per CU, 4: two 64-sample tiles per CU)
   PP_OPT_NERF_CHAIN_HEAD,      // scene branch: 1 = the colour head's hidden layer as a ninth stage of the fused forward chain
+  PP_OPT_NERF_TN_TR,           // scene branch: 1 = weight-gradient kernel with row-major LDS images and transposed fragment reads (k_gemm_tn_tr)
   PP_OPT_COUNT
 };
 

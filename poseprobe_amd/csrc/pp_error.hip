@@ -27,6 +27,7 @@ static const PPOptionDef g_opt_def[PP_OPT_COUNT] = {
     {"wgrad_side_wgs", 0, 0, 4096}, {"side_stream", 0, 0, 2},
     {"nerf_chain", 3, 0, 3},       {"nerf_chain_nw", 4, 4, 8},
     {"nerf_chain_head", 1, 0, 1},
+    {"nerf_tn_tr", 1, 0, 1},
 };
 // compiled-in defaults: constants, never written after static initialisation
 static const struct PPDefaults {

@@ -335,6 +335,183 @@ static __global__ __launch_bounds__(256) void k_gemm_tn_split(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The same product with ROW-MAJOR LDS images and hardware-transposed fragment reads (gfx950 ds_read_b64_tr_b16).
+// k_gemm_tn_split transposes on the way INTO LDS: 16-byte stores of eight rows of one column, 4-way bank conflicts by
+// construction - on the LDS store path (13 cycles per conflict-free ds_write_b128 already, MI355X_MICROARCH.md LDS table) that
+// is ~32 cycles per wave-instruction, 64 of them per chunk and work-group: more LDS time than the chunk's matrix instructions
+// (PMC: matrix pipe busy 25 %).  Here a thread stores what it loaded - four consecutive columns of a row, hi and lo, as 8-byte
+// conflict-free stores into [64 rows][128 halfs] images with 256-byte rows whose 16-byte chunks are XOR-swizzled
+// (cdna_hip_programming.md T10, image (b)) - and a fragment (eight consecutive rows of one column per lane) is two transposed
+// reads of 4 rows x 16 columns per 16-lane group.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+#if defined(TN_TIMERS) && defined(PP_NERF_TU)      // phase timers (experiments, scene translation unit only): wave 0 of every work-group sums s_memtime deltas per phase
+#define TN_TIMERS_ON 1
+__device__ unsigned long long g_tn_t[8];
+extern "C" int pp_debug_read_tn_timers(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tn_t), sizeof(g_tn_t)) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tn_t), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
+static __global__ __launch_bounds__(256, 2) void k_gemm_tn_tr(const float* __restrict__ Y_, int ldy, const float* __restrict__ X_, int ldx,
+                                                          int Kx_, float* __restrict__ Wbar_, int ldwb, float* __restrict__ bbar_,
+                                                          const int32_t* __restrict__ count, int rcap,
+                                                          const float* __restrict__ y_max, const float* __restrict__ x_max) {
+  constexpr int CH = 64;
+  __shared__ __attribute__((aligned(1024))) unsigned char img[4 * CH * 256];       // Yh | Yl | Xh | Xl
+  unsigned char* const Yh = img;
+  unsigned char* const Yl = img + CH * 256;
+  unsigned char* const Xh = img + 2 * CH * 256;
+  unsigned char* const Xl = img + 3 * CH * 256;
+  const int nkb = (Kx_ + 127) >> 7;
+  const int nb = blockIdx.y / nkb, kb = blockIdx.y - nb * nkb;
+  const float* __restrict__ Y = Y_ + nb * 128;
+  const float* __restrict__ X = X_ + kb * 128;
+  const int Kx = min(128, Kx_ - kb * 128);
+  float* __restrict__ Wbar = Wbar_ + (size_t)nb * 128 * ldwb + kb * 128;
+  float* __restrict__ bbar = (bbar_ && kb == 0) ? bbar_ + nb * 128 : nullptr;
+  const int R = min(count[0], rcap);
+  const int rows_per_wg = ((R + (int)gridDim.x - 1) / (int)gridDim.x + CH - 1) / CH * CH;
+  const int rb = blockIdx.x * rows_per_wg;
+  if (rb >= R) return;
+  const int re = min(rb + rows_per_wg, R);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const float sY = pp_split_scale(y_max[0]), sX = pp_split_scale(x_max[0]);
+  const int c4 = tid & 31, rblk = tid >> 5;                 // this thread: columns 4 c4 .. 4 c4 + 3, rows 8 rblk .. 8 rblk + 7
+  const int kx4 = Kx >> 2;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 ry[8], rx[8];
+  auto load_rows = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int gr = r0 + rblk * 8 + i;
+      ry[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rx[i] = ry[i];
+      if (gr < re) {
+        ry[i] = *reinterpret_cast<const float4*>(Y + (size_t)gr * ldy + c4 * 4);
+        if (c4 < kx4) rx[i] = *reinterpret_cast<const float4*>(X + (size_t)gr * ldx + c4 * 4);
+      }
+    }
+  };
+  // transposed fragment: lane (group g = lane / 16, q = (lane & 15) / 4, p = lane & 3) addresses row q, columns 4 p .. 4 p + 3 of its
+  // group's 4 x 16 block and receives column (lane & 15) of the block's four rows; two blocks = the eight rows of the lane's half
+  typedef __fp16 tn_h4 __attribute__((vector_size(8)));
+  const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+  auto frag = [&](const unsigned char* plane, int cb, int ks) -> pp_half8 {        // cb: first of the tile's 32 columns, ks: first of its 16 rows
+    const int ch = ((cb + 16 * (fg & 1)) >> 3) + (fp >> 1);
+    const int row = ks + 8 * (fg >> 1) + fq;
+    const tn_h4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tn_h4*)(plane + tn_off(row, ch) + 8 * (fp & 1)));
+    const tn_h4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tn_h4*)(plane + tn_off(row + 4, ch) + 8 * (fp & 1)));
+    typedef __fp16 tn_h8 __attribute__((vector_size(16)));
+    const tn_h8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(pp_half8, v);
+  };
+#ifdef TN_TIMERS_ON
+  unsigned long long tsum[8] = {0}, tprev = __builtin_readcyclecounter();
+#define TN_TICK(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); tsum[i] += t__ - tprev; tprev = t__; } while (0)
+#else
+#define TN_TICK(i) do {} while (0)
+#endif
+  load_rows(rb);
+  for (int r0 = rb; r0 < re; r0 += CH) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TN_TICK(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int o = tn_off(rblk * 8 + i, c4 >> 1) + 8 * (c4 & 1);
+      pp_half4 h, l;
+      pp_split4(ry[i], sY, h, l);
+      *reinterpret_cast<pp_half4*>(Yh + o) = h;
+      *reinterpret_cast<pp_half4*>(Yl + o) = l;
+      pp_split4(rx[i], sX, h, l);
+      *reinterpret_cast<pp_half4*>(Xh + o) = h;
+      *reinterpret_cast<pp_half4*>(Xl + o) = l;
+    }
+    if (bbar) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { bsum[0] += ry[i].x; bsum[1] += ry[i].y; bsum[2] += ry[i].z; bsum[3] += ry[i].w; }
+    }
+    TN_TICK(1);
+    __syncthreads();
+    TN_TICK(2);
+    if (r0 + CH < re) load_rows(r0 + CH);
+    if (wc * 64 < Kx) {                                       // (uniform per wavefront: the transposed reads need all 64 lanes)
+      // fragments of the next 16 rows are on their way while the matrix instructions of these 16 issue (left in one loop
+      // body, the compiler reads a step's ten fragments only after the previous step's last matrix instruction: four exposed
+      // LDS round trips per chunk - phase timers: 4.4 k ticks per chunk of 48 matrix instructions)
+      pp_half8 fa[2][4], fb[2][4];                          // [parity][tile 0 hi, tile 0 lo, tile 1 hi, tile 1 lo]
+      auto fetch = [&](int par, int ks) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { fa[par][2 * t] = frag(Yh, wr * 64 + t * 32, ks); fa[par][2 * t + 1] = frag(Yl, wr * 64 + t * 32, ks); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { fb[par][2 * u] = frag(Xh, wc * 64 + u * 32, ks); fb[par][2 * u + 1] = frag(Xl, wc * 64 + u * 32, ks); }
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int s4 = 0; s4 < CH / 16; ++s4) {
+        const int par = s4 & 1;
+        if (s4 + 1 < CH / 16) fetch(par ^ 1, (s4 + 1) * 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][2 * t + 1], fb[par][2 * u], acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][2 * t], fb[par][2 * u + 1], acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][2 * t], fb[par][2 * u], acc[t][u], 0, 0, 0);
+          }
+      }
+    }
+    TN_TICK(3);
+    __syncthreads();
+    TN_TICK(4);
+  }
+  const float inv = 1.0f / (sY * sX);
+  if (wc * 64 < Kx) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = wc * 64 + u * 32 + l31;
+        if (k >= Kx) continue;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int n = wr * 64 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+          atomicAdd(&Wbar[(size_t)n * ldwb + k], acc[t][u][reg] * inv);
+        }
+      }
+  }
+  if (bbar) {                              // 8 row blocks x 128 columns of partial sums -> one atomic per column
+    float* red = reinterpret_cast<float*>(img);           // the operand images are dead (last chunk ended with a barrier)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rblk * 128 + c4 * 4 + j] = bsum[j];
+    __syncthreads();
+    if (tid < 128) {
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sum += red[q * 128 + tid];
+      atomicAdd(&bbar[tid], sum);
+    }
+  }
+#ifdef TN_TIMERS_ON
+  TN_TICK(5);
+  if (tid == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_tn_t[i], tsum[i]);
+#endif
+#undef TN_TICK
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Self-scaling variant of k_gemm_tn_split for callers that have no operand maxima (the object branch's layer-fused kernels
 // do not record any):  Wbar[n][k] += sum_r Y[r][n] X[r][k],  n < 128, k < Kx <= 128, Y and X with 128 / ldx floats per row.
 // Every 64-row chunk reduces max|Y|, max|X| of what it is about to stage (registers -> wave shuffle -> 8 floats of LDS) and

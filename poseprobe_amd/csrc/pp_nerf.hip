@@ -18,6 +18,7 @@
 // With the three-product scheme the matrix time drops to a third and the GEMMs become load-bound.  The thin
 // ends of the network (encoding, density head, 128 -> 3 colour head, compositing, encoding backward) are bandwidth-bound
 // streaming kernels.
+#define PP_NERF_TU 1
 #include "pp_common.h"
 #include "pp_gemm.h"
 #include "pp_gemm_split.h"
@@ -748,7 +749,8 @@ static void nerf_gemm_tn(hipStream_t st, const float* Y, int ldy, int N, const f
                                                            // is three instructions per pair: 2.90 vs 2.99 ms per scene step (round 1, with the
                                                            // compiler's conversion: one per CU was best, 3.69 vs 3.85 ms)
     dim3 gs(NERF_TN_SPLIT_WGS * 4 / blocks, blocks);
-    hipLaunchKernelGGL(k_gemm_tn_split, gs, b, 0, st, Y, ldy, X, ldx, Kx, Wbar, ldx, bbar, count, rows, y_max, x_max);
+    if (pp_opt(PP_OPT_NERF_TN_TR) == 1) hipLaunchKernelGGL(k_gemm_tn_tr, gs, b, 0, st, Y, ldy, X, ldx, Kx, Wbar, ldx, bbar, count, rows, y_max, x_max);
+    else hipLaunchKernelGGL(k_gemm_tn_split, gs, b, 0, st, Y, ldy, X, ldx, Kx, Wbar, ldx, bbar, count, rows, y_max, x_max);
     return;
   }
   dim3 g(NERF_TN_WGS * 4 / blocks, blocks);               // ~ 4 x NERF_TN_WGS work-groups whatever the block count (2, 3, 4 or 6)
