@@ -344,6 +344,9 @@ static __global__ __launch_bounds__(256) void k_gemm_tn_split(const float* __res
 // (cdna_hip_programming.md T10, image (b)) - and a fragment (eight consecutive rows of one column per lane) is two transposed
 // reads of 4 rows x 16 columns per 16-lane group.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef TN_DBG
+#define TN_DBG 0      // experiments only (k_gemm_tn_tr), bit mask: 1 no row fetches in the loop, 2 fragments read once per chunk
+#endif
 __device__ __forceinline__ int tn_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
 #if defined(TN_TIMERS) && defined(PP_NERF_TU)      // phase timers (experiments, scene translation unit only): wave 0 of every work-group sums s_memtime deltas per phase
@@ -391,17 +394,19 @@ static __global__ __launch_bounds__(256, 2) void k_gemm_tn_tr(const float* __res
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  // rows i0 .. i1 - 1 of this thread's eight of the chunk at r0: clamped addresses, no branches (rows past the range and columns
+  // past Kx are zeroed when they are converted) - the fetches of the next chunk are issued in FOUR pieces between the matrix
+  // instructions of this one.  All sixteen in front of them cost 2 k ticks per chunk (phase timers with the fetches removed:
+  // matrix phase 4.5 k -> 2.5 k): 8 wavefronts x 16 KB pass the CU's 64 B / clock address-and-data path in ~2 k cycles, and a
+  // wavefront's matrix instructions cannot issue before the fetches in front of them have
   float4 ry[8], rx[8];
-  auto load_rows = [&](int r0) {
+  auto load_rows = [&](int r0, int i0, int i1) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int gr = r0 + rblk * 8 + i;
-      ry[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      rx[i] = ry[i];
-      if (gr < re) {
-        ry[i] = *reinterpret_cast<const float4*>(Y + (size_t)gr * ldy + c4 * 4);
-        if (c4 < kx4) rx[i] = *reinterpret_cast<const float4*>(X + (size_t)gr * ldx + c4 * 4);
-      }
+      if (i < i0 || i >= i1) continue;
+      const int gr = min(r0 + rblk * 8 + i, R - 1);
+      ry[i] = *reinterpret_cast<const float4*>(Y + (size_t)gr * ldy + c4 * 4);
+      rx[i] = *reinterpret_cast<const float4*>(X + (size_t)gr * ldx + (c4 < kx4 ? c4 : 0) * 4);
     }
   };
   // transposed fragment: lane (group g = lane / 16, q = (lane & 15) / 4, p = lane & 3) addresses row q, columns 4 p .. 4 p + 3 of its
@@ -423,13 +428,16 @@ static __global__ __launch_bounds__(256, 2) void k_gemm_tn_tr(const float* __res
 #else
 #define TN_TICK(i) do {} while (0)
 #endif
-  load_rows(rb);
+  load_rows(rb, 0, 8);
   for (int r0 = rb; r0 < re; r0 += CH) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TN_TICK(0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int o = tn_off(rblk * 8 + i, c4 >> 1) + 8 * (c4 & 1);
+      const float ky = (r0 + rblk * 8 + i < re) ? 1.f : 0.f, kx = (c4 < kx4) ? ky : 0.f;
+      ry[i].x *= ky; ry[i].y *= ky; ry[i].z *= ky; ry[i].w *= ky;
+      rx[i].x *= kx; rx[i].y *= kx; rx[i].z *= kx; rx[i].w *= kx;
       pp_half4 h, l;
       pp_split4(ry[i], sY, h, l);
       *reinterpret_cast<pp_half4*>(Yh + o) = h;
@@ -445,7 +453,6 @@ static __global__ __launch_bounds__(256, 2) void k_gemm_tn_tr(const float* __res
     TN_TICK(1);
     __syncthreads();
     TN_TICK(2);
-    if (r0 + CH < re) load_rows(r0 + CH);
     if (wc * 64 < Kx) {                                       // (uniform per wavefront: the transposed reads need all 64 lanes)
       // fragments of the next 16 rows are on their way while the matrix instructions of these 16 issue (left in one loop
       // body, the compiler reads a step's ten fragments only after the previous step's last matrix instruction: four exposed
@@ -461,16 +468,25 @@ static __global__ __launch_bounds__(256, 2) void k_gemm_tn_tr(const float* __res
 #pragma unroll
       for (int s4 = 0; s4 < CH / 16; ++s4) {
         const int par = s4 & 1;
-        if (s4 + 1 < CH / 16) fetch(par ^ 1, (s4 + 1) * 16);
+        if (s4 + 1 < CH / 16 && !(TN_DBG & 2)) fetch(par ^ 1, (s4 + 1) * 16);
+        if (TN_DBG & 2) { for (int i = 0; i < 4; ++i) { fa[par ^ 1][i] = fa[par][i]; fb[par ^ 1][i] = fb[par][i]; } }
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][2 * t + 1], fb[par][2 * u], acc[t][u], 0, 0, 0);
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][2 * t], fb[par][2 * u + 1], acc[t][u], 0, 0, 0);
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][2 * t], fb[par][2 * u], acc[t][u], 0, 0, 0);
           }
+          if (t == 0 && !(TN_DBG & 1)) {                    // a quarter of the next chunk's rows behind the first six matrix instructions
+            __builtin_amdgcn_sched_barrier(0);
+            load_rows(r0 + CH, 2 * s4, 2 * s4 + 2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
+    } else if (!(TN_DBG & 1)) {
+      load_rows(r0 + CH, 0, 8);                               // a wavefront without columns in this block still stages its rows
     }
     TN_TICK(3);
     __syncthreads();
