@@ -406,7 +406,8 @@ static __global__ __launch_bounds__(256, 2) void k_gemm_tn_tr(const float* __res
       if (i < i0 || i >= i1) continue;
       const int gr = min(r0 + rblk * 8 + i, R - 1);
       ry[i] = *reinterpret_cast<const float4*>(Y + (size_t)gr * ldy + c4 * 4);
-      rx[i] = *reinterpret_cast<const float4*>(X + (size_t)gr * ldx + (c4 < kx4 ? c4 : 0) * 4);
+      if (TN_DBG & 4) rx[i] = ry[i];                        // experiment: half the bytes
+      else rx[i] = *reinterpret_cast<const float4*>(X + (size_t)gr * ldx + (c4 < kx4 ? c4 : 0) * 4);
     }
   };
   // transposed fragment: lane (group g = lane / 16, q = (lane & 15) / 4, p = lane & 3) addresses row q, columns 4 p .. 4 p + 3 of its
