@@ -541,7 +541,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_nerf_trunk(TrunkAr
       TR_TICK(5);
     }
   }
-  if (tid < 8) atomicMax(reinterpret_cast<unsigned int*>(T.mx + T.mx_out[tid]), __float_as_uint(lmax[tid]));
+  if (tid < 8) pp_record_max_lane(T.mx + T.mx_out[tid], lmax[tid]);      // (skips the atomic when the slot already holds as much: 512 work-groups end together)
 #ifdef TR_TIMERS
   if (tid == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&g_tr_t[(BWD ? 8 : 0) + i], tsum[i]);
