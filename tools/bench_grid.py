@@ -15,7 +15,7 @@ nvox = G ** 3
 hit = (torch.rand(nvox // 4, device=dev) < frac).repeat_interleave(4)
 touched = hit.to(torch.uint8)
 other = torch.zeros(nvox, dtype=torch.uint8, device=dev)
-tv = torch.zeros(1, device=dev)
+tv = torch.zeros(1, device=dev) if os.environ.get('NO_TV') != '1' else None      # NO_TV=1: no TV value (no same-address atomic per work-group)
 print(f'G={G} marked {float(hit.float().mean()):.3f}')
 def run(sparse, n=20):
     a = (p, po, g, m, v, (G, G, G), C, 0, G, 1e-4, 1.0, 0.1, 0.9, 0.99, 1e-8, 3, tv)
